@@ -1,0 +1,88 @@
+// az_common.h -- data layout shared by the host engine and the gfx950 kernels.
+//
+// Node pool (per GPU):  n_trees arenas of `cap` fixed-size records.
+//   record(tree t, slot i) at nodes + ((size_t)t * cap + i) * REC_BYTES, holding
+//   the dense child statistics of ONE position, lane-blocked: lane L of the
+//   wavefront that owns the tree works on actions [L*EPL, L*EPL+EPL), EPL =
+//   ceil(S*S/64), SP = 64*EPL padded actions:
+//       N    int32  [SP]   visit counts          (Node::childN, node.h:46)
+//       LINK int32  [SP]   child slot + 1, 0=null (Node::child,  node.h:44)
+//       W    double [SP]   value sums            (Node::childW, node.h:47)
+//       P    double [SP]   priors                (Node::childP, node.h:37)
+//   node_n[t*cap+i]  int32: Node::nodeN (node.h:35) of an expanded node
+//   parent[t*cap+i]  int32: parent slot, -1 for a root, -2 for a free slot
+//   free_stack[t*cap + k], k < free_top: free slots, popped from the top
+//   order[t*cap + k],  k < n_order: live slots in allocation order (a parent
+//                      always precedes its children), used by re-rooting
+// Per tree: AzTree header, plus the board twice in wave layout:
+//   rows[t*64 + L]: bit c = stone at (row L&31, col c) of plane L>>5
+//   occ [t*64 + L]: bit k = action L*EPL+k occupied (either plane)
+#ifndef AZ_COMMON_H
+#define AZ_COMMON_H
+
+#include <stdint.h>
+
+#define AZ_MAX_SHAPE 20
+// board edges compiled into the library (keep in step with SHAPES in the Makefile)
+#define AZ_SHAPE_LIST(X) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20)
+
+struct AzTree {
+    int root;        // slot of the root node, -1 while the root is unexpanded (nodeN == -1)
+    int free_top;    // entries in this tree's free stack
+    int n_order;     // live slots
+    int player;      // 0/1 to move               (State::player,  state.h:42)
+    int move_cnt;    //                           (State::move_cnt, state.h:43)
+    float winner;    // -1, 0, 1, 0.5             (State::winner,  state.h:44)
+    int err;         // first AZ_ERR_* raised inside a kernel for this tree
+    int active;      // takes part in simulate / select
+    int noise_row;   // next row of the noise table (restarts per simulate call)
+    int leaf_kind;   // AZ_LEAF_* of the pending step (select -> expand_backup)
+    int path_len;    // depth of the pending step's path
+    float leaf_value;// value of a terminal leaf of the pending step
+    unsigned long long stats[4]; // sims, expansions, terminals, select calls
+};
+
+struct AzParams {
+    char *nodes;
+    int *node_n;
+    int *parent;
+    int *free_stack;
+    int *order;
+    AzTree *trees;
+    unsigned *rows;
+    unsigned *occ;
+    int *path_node;   // [n_trees][path_cap] slots along the pending path
+    int *path_act;    // [n_trees][path_cap]
+    const double *noise; // [noise_rows][SP] or null
+    int noise_rows;
+    int n_trees;
+    int cap;
+    int path_cap;
+    double cpuct;
+    double eps;
+};
+
+struct AzFusedArgs {
+    int n_total;         // searches per tree in this launch
+    int per_worker;      // noise stream restarts every per_worker searches
+    int eval_kind;
+    float const_prior;
+    float const_value;
+    unsigned long long hash_seed;
+};
+
+// launchers exported by each per-shape translation unit (az_kernels.hip built
+// with -DAZ_S=<shape>); the engine picks the table entry of its shape.
+struct AzShapeOps {
+    int shape;
+    int (*simulate_fused)(const AzParams &, const AzFusedArgs &, void *stream);
+    int (*select)(const AzParams &, float *d_boards, int *d_leaf_kind, void *stream);
+    int (*expand_backup)(const AzParams &, const float *d_value, const float *d_prior,
+                         int prior_is_log, void *stream);
+    int (*make_move)(const AzParams &, const int *d_actions, void *stream);
+    int (*clear)(const AzParams &, const unsigned char *d_mask, void *stream);
+    int (*select_greedy)(const AzParams &, int *d_actions, void *stream);
+    int (*get_counts)(const AzParams &, int *d_counts, int *d_root_n, void *stream);
+};
+
+#endif

@@ -1,0 +1,672 @@
+// az_engine.cpp -- host side of libazmcts.so: node-pool allocation, shape
+// dispatch and the C ABI declared in include/azmcts.h.  No torch types, no
+// CPU search path: every search entry point launches gfx950 kernels.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstddef>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/azmcts.h"
+#include "az_common.h"
+
+#define AZ_DECL(s) extern "C" const AzShapeOps *az_shape_ops_##s(void);
+AZ_SHAPE_LIST(AZ_DECL)
+#undef AZ_DECL
+
+namespace {
+
+thread_local char g_err[512];
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(AZ_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));            \
+    } while (0)
+
+const AzShapeOps *find_ops(int shape)
+{
+#define AZ_PICK(s) \
+    if (shape == s) return az_shape_ops_##s();
+    AZ_SHAPE_LIST(AZ_PICK)
+#undef AZ_PICK
+    return nullptr;
+}
+
+} // namespace
+
+struct az_engine {
+    int device = 0;
+    int n_trees = 0, shape = 0, size = 0, epl = 0, sp = 0, cap = 0;
+    size_t rec_bytes = 0;
+    const AzShapeOps *ops = nullptr;
+    AzParams P{};
+    double alpha = 1.0;
+    int threads = 0;
+    int cuda = 0;
+    unsigned long long device_bytes = 0;
+    // device scratch
+    int *d_actions = nullptr;      // [n_trees]
+    unsigned char *d_mask = nullptr; // [n_trees]
+    int *d_counts = nullptr;       // [n_trees][size]
+    int *d_root_n = nullptr;       // [n_trees]
+    double *d_noise = nullptr;     // [rows][sp]
+    std::vector<AzTree> h_trees;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+template <typename T> int dev_alloc(az_engine *e, T **p, size_t count)
+{
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    HIP_TRY(hipMalloc((void **)p, bytes));
+    e->device_bytes += bytes;
+    return AZ_OK;
+}
+
+int fetch_trees(az_engine *e)
+{
+    HIP_TRY(hipMemcpy(e->h_trees.data(), e->P.trees, sizeof(AzTree) * e->n_trees, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+int check_tree(const az_engine *e, int tree)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    if (tree < 0 || tree >= e->n_trees) return fail(AZ_ERR_ARG, "tree index %d out of range (0-%d)", tree, e->n_trees - 1);
+    return AZ_OK;
+}
+
+const char *kernel_err_text(int code)
+{
+    switch (code) {
+    case AZ_ERR_POOL_FULL: return "node pool exhausted";
+    case AZ_ERR_NO_ACTION: return "No action chosen. Incorrect behaviour";
+    case AZ_ERR_NOISE_ROWS: return "noise table exhausted";
+    case AZ_ERR_INVALID_MOVE: return "Invalid move";
+    default: return "kernel error";
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+const char *az_last_error(void) { return g_err; }
+
+#ifndef AZ_GIT
+#define AZ_GIT "unknown"
+#endif
+const char *az_version(void) { return AZ_GIT; }
+const char *az_build_timestamp(void) { return __DATE__ " " __TIME__; }
+
+int az_create(az_engine **out, int device, int n_trees, int shape, int nodes_per_tree, double alpha, double cpuct)
+{
+    if (!out) return fail(AZ_ERR_ARG, "null output pointer");
+    *out = nullptr;
+    const AzShapeOps *ops = find_ops(shape);
+    if (!ops) return fail(AZ_ERR_ARG, "board shape %d is not compiled into this library", shape);
+    if (n_trees < 1) return fail(AZ_ERR_ARG, "n_trees must be at least 1");
+    if (nodes_per_tree < 2 || nodes_per_tree > (1 << 19))
+        return fail(AZ_ERR_ARG, "nodes_per_tree must be in 2..524288");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(AZ_ERR_ARG, "device %d not present (%d visible)", device, ndev);
+
+    az_engine *e = new az_engine();
+    e->device = device;
+    DeviceGuard g(device);
+    if (!g.ok) { delete e; return fail(AZ_ERR_HIP, "hipSetDevice(%d) failed", device); }
+    e->n_trees = n_trees;
+    e->shape = shape;
+    e->size = shape * shape;
+    e->epl = (e->size + 63) / 64;
+    e->sp = 64 * e->epl;
+    e->cap = nodes_per_tree;
+    e->rec_bytes = (size_t)e->sp * 24;
+    e->ops = ops;
+    e->alpha = alpha;
+    AzParams &P = e->P;
+    P.n_trees = n_trees;
+    P.cap = nodes_per_tree;
+    P.path_cap = e->size + 1;
+    P.cpuct = cpuct;
+    P.eps = 0.25; // cmcts.cpp:8
+    P.noise = nullptr;
+    P.noise_rows = 0;
+    const size_t slots = (size_t)n_trees * nodes_per_tree;
+    int rc = AZ_OK;
+    if (!rc) rc = dev_alloc(e, &P.nodes, slots * e->rec_bytes);
+    if (!rc) rc = dev_alloc(e, &P.node_n, slots);
+    if (!rc) rc = dev_alloc(e, &P.parent, slots);
+    if (!rc) rc = dev_alloc(e, &P.free_stack, slots);
+    if (!rc) rc = dev_alloc(e, &P.order, slots);
+    if (!rc) rc = dev_alloc(e, &P.trees, (size_t)n_trees);
+    if (!rc) rc = dev_alloc(e, &P.rows, (size_t)n_trees * 64);
+    if (!rc) rc = dev_alloc(e, &P.occ, (size_t)n_trees * 64);
+    if (!rc) rc = dev_alloc(e, &P.path_node, (size_t)n_trees * P.path_cap);
+    if (!rc) rc = dev_alloc(e, &P.path_act, (size_t)n_trees * P.path_cap);
+    if (!rc) rc = dev_alloc(e, &e->d_actions, (size_t)n_trees);
+    if (!rc) rc = dev_alloc(e, &e->d_mask, (size_t)n_trees);
+    if (!rc) rc = dev_alloc(e, &e->d_counts, (size_t)n_trees * e->size);
+    if (!rc) rc = dev_alloc(e, &e->d_root_n, (size_t)n_trees);
+    if (rc) { az_destroy(e); return rc; }
+
+    // initial pool state: every slot free, stack pops 0,1,2,...
+    {
+        std::vector<int> stack(slots), par(slots, -2);
+        for (int t = 0; t < n_trees; t++)
+            for (int k = 0; k < nodes_per_tree; k++) stack[(size_t)t * nodes_per_tree + k] = nodes_per_tree - 1 - k;
+        hipError_t he = hipMemcpy(P.free_stack, stack.data(), slots * sizeof(int), hipMemcpyHostToDevice);
+        if (he == hipSuccess) he = hipMemcpy(P.parent, par.data(), slots * sizeof(int), hipMemcpyHostToDevice);
+        if (he == hipSuccess) he = hipMemset(P.rows, 0, (size_t)n_trees * 64 * sizeof(unsigned));
+        if (he == hipSuccess) he = hipMemset(P.occ, 0, (size_t)n_trees * 64 * sizeof(unsigned));
+        e->h_trees.assign(n_trees, AzTree{});
+        for (auto &t : e->h_trees) {
+            t.root = -1;
+            t.free_top = nodes_per_tree;
+            t.winner = -1.f;
+            t.active = 1;
+        }
+        if (he == hipSuccess)
+            he = hipMemcpy(P.trees, e->h_trees.data(), sizeof(AzTree) * n_trees, hipMemcpyHostToDevice);
+        if (he == hipSuccess) he = hipEventCreate(&e->ev0);
+        if (he == hipSuccess) he = hipEventCreate(&e->ev1);
+        if (he != hipSuccess) {
+            az_destroy(e);
+            return fail(AZ_ERR_HIP, "engine initialisation failed: %s", hipGetErrorString(he));
+        }
+    }
+    *out = e;
+    return AZ_OK;
+}
+
+void az_destroy(az_engine *e)
+{
+    if (!e) return;
+    DeviceGuard g(e->device);
+    (void)hipDeviceSynchronize();
+    AzParams &P = e->P;
+    void *ptrs[] = {P.nodes, P.node_n, P.parent, P.free_stack, P.order, P.trees, P.rows, P.occ,
+                    P.path_node, P.path_act, e->d_actions, e->d_mask, e->d_counts, e->d_root_n, e->d_noise};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    delete e;
+}
+
+int az_n_trees(const az_engine *e) { return e ? e->n_trees : 0; }
+int az_shape(const az_engine *e) { return e ? e->shape : 0; }
+int az_nodes_per_tree(const az_engine *e) { return e ? e->cap : 0; }
+unsigned long long az_device_bytes(const az_engine *e) { return e ? e->device_bytes : 0; }
+
+int az_set_eps(az_engine *e, double eps)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    if (eps > 1. || eps < 0.) return fail(AZ_ERR_EPS_RANGE, "Epsilon must be in range <0,1>");
+    e->P.eps = eps;
+    return AZ_OK;
+}
+double az_get_eps(const az_engine *e) { return e->P.eps; }
+int az_set_cpuct(az_engine *e, float cpuct)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    e->P.cpuct = cpuct; // float argument widened into the double member (cmcts.cpp:58, cmcts.h:76)
+    return AZ_OK;
+}
+float az_get_cpuct(const az_engine *e) { return (float)e->P.cpuct; }
+int az_set_alpha(az_engine *e, double alpha)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    e->alpha = alpha;
+    return AZ_OK;
+}
+double az_get_alpha(const az_engine *e) { return e->alpha; }
+int az_set_alpha_default(az_engine *e)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    double len = e->shape * 2; // average game length estimate (cmcts.cpp:78)
+    double num = (e->size * len - (len * len + len) * 0.5) / len;
+    e->alpha = 10 / num;
+    return AZ_OK;
+}
+int az_set_threads(az_engine *e, int threads)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    e->threads = threads;
+    return AZ_OK;
+}
+int az_get_threads(const az_engine *e) { return e->threads; }
+int az_set_cuda(az_engine *e, int cuda)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    // the reference's guard `cuda != 1 || cuda != 0` holds for every int, so its
+    // setter always throws (cmcts.cpp:70); kept: the evaluator device is not chosen here
+    (void)cuda;
+    return fail(AZ_ERR_INVALID_VALUE, "Invalid value");
+}
+int az_get_cuda(const az_engine *e) { return e->cuda; }
+
+int az_set_player(az_engine *e, int tree, int player)
+{
+    if (int rc = check_tree(e, tree)) return rc;
+    if (player != 0 && player != 1) return fail(AZ_ERR_ARG, "player must be 0 or 1");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy((char *)(e->P.trees + tree) + offsetof(AzTree, player), &player, sizeof(int),
+                      hipMemcpyHostToDevice));
+    return AZ_OK;
+}
+
+int az_get_states(az_engine *e, int *player, int *move_cnt, float *winner)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    DeviceGuard g(e->device);
+    if (int rc = fetch_trees(e)) return rc;
+    for (int t = 0; t < e->n_trees; t++) {
+        if (player) player[t] = e->h_trees[t].player;
+        if (move_cnt) move_cnt[t] = e->h_trees[t].move_cnt;
+        if (winner) winner[t] = e->h_trees[t].winner;
+    }
+    return AZ_OK;
+}
+
+int az_get_state(az_engine *e, int tree, int *player, int *move_cnt, float *winner)
+{
+    if (int rc = check_tree(e, tree)) return rc;
+    DeviceGuard g(e->device);
+    AzTree t;
+    HIP_TRY(hipMemcpy(&t, e->P.trees + tree, sizeof t, hipMemcpyDeviceToHost));
+    if (player) *player = t.player;
+    if (move_cnt) *move_cnt = t.move_cnt;
+    if (winner) *winner = t.winner;
+    return AZ_OK;
+}
+
+int az_clear_masked(az_engine *e, const unsigned char *mask)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    DeviceGuard g(e->device);
+    if (mask) {
+        HIP_TRY(hipMemcpy(e->d_mask, mask, e->n_trees, hipMemcpyHostToDevice));
+        if (e->ops->clear(e->P, e->d_mask, nullptr)) return fail(AZ_ERR_HIP, "clear launch failed");
+    } else {
+        if (e->ops->clear(e->P, nullptr, nullptr)) return fail(AZ_ERR_HIP, "clear launch failed");
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    return AZ_OK;
+}
+
+int az_clear(az_engine *e, int tree)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    if (tree < 0) return az_clear_masked(e, nullptr);
+    if (int rc = check_tree(e, tree)) return rc;
+    std::vector<unsigned char> m(e->n_trees, 0);
+    m[tree] = 1;
+    return az_clear_masked(e, m.data());
+}
+
+int az_set_active(az_engine *e, const unsigned char *mask)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipDeviceSynchronize());
+    if (int rc = fetch_trees(e)) return rc;
+    for (int t = 0; t < e->n_trees; t++) e->h_trees[t].active = mask ? (mask[t] != 0) : 1;
+    HIP_TRY(hipMemcpy(e->P.trees, e->h_trees.data(), sizeof(AzTree) * e->n_trees, hipMemcpyHostToDevice));
+    return AZ_OK;
+}
+
+int az_set_noise_table(az_engine *e, const double *noise, int rows)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipDeviceSynchronize());
+    if (e->d_noise) {
+        (void)hipFree(e->d_noise);
+        e->d_noise = nullptr;
+    }
+    e->P.noise = nullptr;
+    e->P.noise_rows = 0;
+    if (rows <= 0 || !noise) return AZ_OK;
+    std::vector<double> padded((size_t)rows * e->sp, 0.0);
+    for (int r = 0; r < rows; r++)
+        memcpy(&padded[(size_t)r * e->sp], noise + (size_t)r * e->size, sizeof(double) * e->size);
+    HIP_TRY(hipMalloc((void **)&e->d_noise, padded.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(e->d_noise, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice));
+    e->P.noise = e->d_noise;
+    e->P.noise_rows = rows;
+    return AZ_OK;
+}
+
+static int check_noise(const az_engine *e)
+{
+    if (e->P.eps != 0. && e->P.noise == nullptr)
+        return fail(AZ_ERR_NOISE_ROWS, "eps != 0 needs a noise table (az_set_noise_table)");
+    return AZ_OK;
+}
+
+int az_simulate_fused(az_engine *e, int n, int eval_kind, float const_prior, float const_value,
+                      unsigned long long hash_seed, void *stream)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    if (n < 1) return fail(AZ_ERR_BAD_SIMS, "Invalid input %d must be at least 1!", n);
+    if (eval_kind != AZ_EVAL_UNIFORM && eval_kind != AZ_EVAL_HASH) return fail(AZ_ERR_NO_PREDICTOR, "Predictor missing!");
+    if (int rc = check_noise(e)) return rc;
+    AzFusedArgs A{};
+    // thread fan-out of cmcts.cpp:98-119: th_num workers of `per` searches each
+    int th_num = 1, per = n;
+    if (e->threads > 1) {
+        th_num = e->threads;
+        if (n < th_num) { th_num = n; per = 1; }
+        else if (n % th_num == 0) per = n / th_num;
+        else per = n / th_num + 1;
+    }
+    A.n_total = th_num * per;
+    A.per_worker = per;
+    A.eval_kind = eval_kind;
+    A.const_prior = const_prior;
+    A.const_value = const_value;
+    A.hash_seed = hash_seed;
+    DeviceGuard g(e->device);
+    if (e->ops->simulate_fused(e->P, A, stream)) return fail(AZ_ERR_HIP, "simulate launch failed");
+    return AZ_OK;
+}
+
+int az_begin_simulate(az_engine *e, void *stream)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    if (int rc = check_noise(e)) return rc;
+    DeviceGuard g(e->device);
+    // noise_row := 0 for every tree: a strided 4-byte memset
+    HIP_TRY(hipMemset2DAsync((char *)e->P.trees + offsetof(AzTree, noise_row), sizeof(AzTree), 0, sizeof(int),
+                             e->n_trees, (hipStream_t)stream));
+    return AZ_OK;
+}
+
+int az_select(az_engine *e, float *d_boards, int *d_leaf_kind, void *stream)
+{
+    if (!e || !d_boards || !d_leaf_kind) return fail(AZ_ERR_ARG, "null argument");
+    DeviceGuard g(e->device);
+    if (e->ops->select(e->P, d_boards, d_leaf_kind, stream)) return fail(AZ_ERR_HIP, "select launch failed");
+    return AZ_OK;
+}
+
+int az_expand_backup(az_engine *e, const float *d_value, const float *d_prior, int prior_is_log, void *stream)
+{
+    if (!e || !d_value || !d_prior) return fail(AZ_ERR_ARG, "null argument");
+    DeviceGuard g(e->device);
+    if (e->ops->expand_backup(e->P, d_value, d_prior, prior_is_log, stream))
+        return fail(AZ_ERR_HIP, "expand_backup launch failed");
+    return AZ_OK;
+}
+
+static int sync_check_impl(az_engine *e, void *stream, int *tree_out)
+{
+    DeviceGuard g(e->device);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (int rc = fetch_trees(e)) return rc;
+    int first = -1;
+    for (int t = 0; t < e->n_trees; t++)
+        if (e->h_trees[t].err) { first = t; break; }
+    if (tree_out) *tree_out = first;
+    if (first < 0) return AZ_OK;
+    const int code = e->h_trees[first].err;
+    // clear the error words (a 4-byte strided memset)
+    HIP_TRY(hipMemset2D((char *)e->P.trees + offsetof(AzTree, err), sizeof(AzTree), 0, sizeof(int), e->n_trees));
+    return fail(code, "%s (tree %d)", kernel_err_text(code), first);
+}
+
+int az_sync_check(az_engine *e, void *stream)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    return sync_check_impl(e, stream, nullptr);
+}
+
+int az_make_move(az_engine *e, const int *actions, int on_device, void *stream)
+{
+    if (!e || !actions) return fail(AZ_ERR_ARG, "null argument");
+    DeviceGuard g(e->device);
+    const int *d_act = actions;
+    if (!on_device) {
+        HIP_TRY(hipMemcpyAsync(e->d_actions, actions, sizeof(int) * e->n_trees, hipMemcpyHostToDevice,
+                               (hipStream_t)stream));
+        d_act = e->d_actions;
+    }
+    if (e->ops->make_move(e->P, d_act, stream)) return fail(AZ_ERR_HIP, "make_move launch failed");
+    if (!on_device) {
+        int tree = -1;
+        int rc = sync_check_impl(e, stream, &tree);
+        if (rc == AZ_ERR_INVALID_MOVE) // worded like State::make_move (state.cpp:85-86)
+            return fail(rc, "Invalid move %d (tree %d)", tree >= 0 ? actions[tree] : -1, tree);
+        return rc;
+    }
+    return AZ_OK;
+}
+
+int az_make_movexy(az_engine *e, int tree, int x, int y)
+{
+    if (int rc = check_tree(e, tree)) return rc;
+    if (y >= e->shape || x >= e->shape) // cmcts.cpp:299-300
+        return fail(AZ_ERR_BAD_XY, "Invalid index y:%d or x: %d (range is 0-%d)!", y, x, e->size);
+    std::vector<int> act(e->n_trees, -1);
+    act[tree] = y * e->shape + x;
+    if (act[tree] < 0) return fail(AZ_ERR_INVALID_MOVE, "Invalid move %d (tree %d)", act[tree], tree);
+    return az_make_move(e, act.data(), 0, nullptr);
+}
+
+int az_select_greedy(az_engine *e, int *d_actions, void *stream)
+{
+    if (!e || !d_actions) return fail(AZ_ERR_ARG, "null argument");
+    DeviceGuard g(e->device);
+    if (e->ops->select_greedy(e->P, d_actions, stream)) return fail(AZ_ERR_HIP, "select_greedy launch failed");
+    return AZ_OK;
+}
+
+int az_get_counts(az_engine *e, int *counts, int *root_n)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    DeviceGuard g(e->device);
+    if (e->ops->get_counts(e->P, e->d_counts, e->d_root_n, nullptr)) return fail(AZ_ERR_HIP, "get_counts launch failed");
+    if (counts)
+        HIP_TRY(hipMemcpy(counts, e->d_counts, sizeof(int) * (size_t)e->n_trees * e->size, hipMemcpyDeviceToHost));
+    if (root_n) HIP_TRY(hipMemcpy(root_n, e->d_root_n, sizeof(int) * e->n_trees, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+// reads one record's arrays of `tree`/`slot` into host vectors
+static int read_slot(az_engine *e, int tree, int slot, int *node_n, std::vector<int> *n, std::vector<int> *link,
+                     std::vector<double> *w, std::vector<double> *p)
+{
+    const char *rec = e->P.nodes + ((size_t)tree * e->cap + slot) * e->rec_bytes;
+    const int sp = e->sp;
+    if (node_n)
+        HIP_TRY(hipMemcpy(node_n, e->P.node_n + (size_t)tree * e->cap + slot, sizeof(int), hipMemcpyDeviceToHost));
+    if (n) { n->resize(sp); HIP_TRY(hipMemcpy(n->data(), rec, sp * 4, hipMemcpyDeviceToHost)); }
+    if (link) { link->resize(sp); HIP_TRY(hipMemcpy(link->data(), rec + (size_t)sp * 4, sp * 4, hipMemcpyDeviceToHost)); }
+    if (w) { w->resize(sp); HIP_TRY(hipMemcpy(w->data(), rec + (size_t)sp * 8, sp * 8, hipMemcpyDeviceToHost)); }
+    if (p) { p->resize(sp); HIP_TRY(hipMemcpy(p->data(), rec + (size_t)sp * 16, sp * 8, hipMemcpyDeviceToHost)); }
+    return AZ_OK;
+}
+
+int az_get_prob(az_engine *e, int tree, float *prob)
+{
+    if (int rc = check_tree(e, tree)) return rc;
+    if (!prob) return fail(AZ_ERR_ARG, "null argument");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipDeviceSynchronize());
+    AzTree t;
+    HIP_TRY(hipMemcpy(&t, e->P.trees + tree, sizeof t, hipMemcpyDeviceToHost));
+    std::vector<int> n(e->sp, 0);
+    int node_n = -1; // unexpanded root (node.cpp:6)
+    if (t.root >= 0)
+        if (int rc = read_slot(e, tree, t.root, &node_n, &n, nullptr, nullptr, nullptr)) return rc;
+    // cmcts.cpp:323-339
+    const double sum = (double)node_n;
+    double prob_sum = 0;
+    for (int i = 0; i < e->size; i++) {
+        prob[i] = (float)((double)n[i] / sum);
+        prob_sum += prob[i];
+    }
+    if (std::round(prob_sum * 1000.) != 1000) return fail(AZ_ERR_NOT_DIST, "Not a distribution");
+    return AZ_OK;
+}
+
+int az_get_raw_board(az_engine *e, int tree, signed char *board)
+{
+    if (int rc = check_tree(e, tree)) return rc;
+    if (!board) return fail(AZ_ERR_ARG, "null argument");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned rows[64];
+    HIP_TRY(hipMemcpy(rows, e->P.rows + (size_t)tree * 64, sizeof rows, hipMemcpyDeviceToHost));
+    const int S = e->shape;
+    for (int pl = 0; pl < 2; pl++)
+        for (int r = 0; r < S; r++)
+            for (int c = 0; c < S; c++) board[pl * e->size + r * S + c] = (signed char)((rows[pl * 32 + r] >> c) & 1u);
+    return AZ_OK;
+}
+
+int az_get_board(az_engine *e, int tree, float *board)
+{
+    if (int rc = check_tree(e, tree)) return rc;
+    if (!board) return fail(AZ_ERR_ARG, "null argument");
+    std::vector<signed char> raw((size_t)2 * e->size);
+    if (int rc = az_get_raw_board(e, tree, raw.data())) return rc;
+    int player = 0;
+    if (int rc = az_get_state(e, tree, &player, nullptr, nullptr)) return rc;
+    // state.cpp:43-44: planes swapped when player == 1
+    for (int pl = 0; pl < 2; pl++) {
+        const int src = player == 1 ? 1 - pl : pl;
+        for (int i = 0; i < e->size; i++) board[pl * e->size + i] = (float)raw[src * e->size + i];
+    }
+    return AZ_OK;
+}
+
+int az_get_node(az_engine *e, int tree, const int *path, int len, int *found, int *node_n, int *counts, double *w,
+                double *p)
+{
+    if (int rc = check_tree(e, tree)) return rc;
+    if (!found || (len > 0 && !path)) return fail(AZ_ERR_ARG, "null argument");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipDeviceSynchronize());
+    *found = 0;
+    AzTree t;
+    HIP_TRY(hipMemcpy(&t, e->P.trees + tree, sizeof t, hipMemcpyDeviceToHost));
+    int slot = t.root;
+    if (slot < 0) return AZ_OK;
+    for (int i = 0; i < len; i++) {
+        if (path[i] < 0 || path[i] >= e->size) return fail(AZ_ERR_ARG, "Index is out of bounds"); // node.cpp:139-140
+        int link = 0;
+        const char *rec = e->P.nodes + ((size_t)tree * e->cap + slot) * e->rec_bytes;
+        HIP_TRY(hipMemcpy(&link, rec + (size_t)e->sp * 4 + (size_t)path[i] * 4, sizeof(int), hipMemcpyDeviceToHost));
+        if (link == 0) return AZ_OK;
+        slot = link - 1;
+    }
+    std::vector<int> n;
+    std::vector<double> vw, vp;
+    if (int rc = read_slot(e, tree, slot, node_n, counts ? &n : nullptr, nullptr, w ? &vw : nullptr, p ? &vp : nullptr))
+        return rc;
+    if (counts) memcpy(counts, n.data(), sizeof(int) * e->size);
+    if (w) memcpy(w, vw.data(), sizeof(double) * e->size);
+    if (p) memcpy(p, vp.data(), sizeof(double) * e->size);
+    *found = 1;
+    return AZ_OK;
+}
+
+int az_get_stats(az_engine *e, unsigned long long *sims, unsigned long long *expansions, unsigned long long *terminals,
+                 unsigned long long *select_calls)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipDeviceSynchronize());
+    if (int rc = fetch_trees(e)) return rc;
+    unsigned long long s[4] = {0, 0, 0, 0};
+    for (const auto &t : e->h_trees)
+        for (int k = 0; k < 4; k++) s[k] += t.stats[k];
+    if (sims) *sims = s[0];
+    if (expansions) *expansions = s[1];
+    if (terminals) *terminals = s[2];
+    if (select_calls) *select_calls = s[3];
+    return AZ_OK;
+}
+
+int az_reset_stats(az_engine *e)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset2D((char *)e->P.trees + offsetof(AzTree, stats), sizeof(AzTree), 0, sizeof(unsigned long long) * 4,
+                        e->n_trees));
+    return AZ_OK;
+}
+
+int az_get_pool_usage(az_engine *e, int tree, int *used, int *max_used)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipDeviceSynchronize());
+    if (int rc = fetch_trees(e)) return rc;
+    if (used) {
+        if (int rc = check_tree(e, tree)) return rc;
+        *used = e->h_trees[tree].n_order;
+    }
+    if (max_used) {
+        int m = 0;
+        for (const auto &t : e->h_trees) m = t.n_order > m ? t.n_order : m;
+        *max_used = m;
+    }
+    return AZ_OK;
+}
+
+int az_timing_begin(az_engine *e, void *stream)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipEventRecord(e->ev0, (hipStream_t)stream));
+    return AZ_OK;
+}
+
+int az_timing_end(az_engine *e, void *stream, float *ms)
+{
+    if (!e || !ms) return fail(AZ_ERR_ARG, "null argument");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipEventRecord(e->ev1, (hipStream_t)stream));
+    HIP_TRY(hipEventSynchronize(e->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, e->ev0, e->ev1));
+    return AZ_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,264 @@
+"""ctypes binding of libazmcts.so (C ABI: include/azmcts.h).
+
+`Engine` owns `n_trees` search trees on one GPU.  Device pointers are passed
+as plain integers (e.g. `tensor.data_ptr()`), streams as the integer handle of
+a hipStream_t (`torch.cuda.current_stream().cuda_stream`).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libazmcts.so")
+
+EVAL_UNIFORM, EVAL_HASH = 0, 1
+LEAF_NONE, LEAF_EXPAND, LEAF_TERMINAL = 0, 1, 2
+
+ERR_INVALID_MOVE, ERR_BAD_SIMS, ERR_NOT_DIST, ERR_EPS_RANGE, ERR_BAD_XY = 1, 2, 3, 4, 5
+ERR_NO_ACTION, ERR_NOISE_ROWS, ERR_INVALID_VALUE, ERR_NO_PREDICTOR = 6, 7, 8, 9
+ERR_POOL_FULL, ERR_ARG, ERR_HIP, ERR_STATE = 10, 11, 12, 13
+
+# every symbol include/azmcts.h declares: (name, restype, argtypes)
+_vp, _i, _d, _f, _ull = C.c_void_p, C.c_int, C.c_double, C.c_float, C.c_ulonglong
+SYMBOLS = [
+    ("az_last_error", C.c_char_p, []),
+    ("az_version", C.c_char_p, []),
+    ("az_build_timestamp", C.c_char_p, []),
+    ("az_create", _i, [C.POINTER(_vp), _i, _i, _i, _i, _d, _d]),
+    ("az_destroy", None, [_vp]),
+    ("az_n_trees", _i, [_vp]),
+    ("az_shape", _i, [_vp]),
+    ("az_nodes_per_tree", _i, [_vp]),
+    ("az_device_bytes", _ull, [_vp]),
+    ("az_set_eps", _i, [_vp, _d]),
+    ("az_get_eps", _d, [_vp]),
+    ("az_set_cpuct", _i, [_vp, _f]),
+    ("az_get_cpuct", _f, [_vp]),
+    ("az_set_alpha", _i, [_vp, _d]),
+    ("az_get_alpha", _d, [_vp]),
+    ("az_set_alpha_default", _i, [_vp]),
+    ("az_set_threads", _i, [_vp, _i]),
+    ("az_get_threads", _i, [_vp]),
+    ("az_set_cuda", _i, [_vp, _i]),
+    ("az_get_cuda", _i, [_vp]),
+    ("az_set_player", _i, [_vp, _i, _i]),
+    ("az_get_state", _i, [_vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f)]),
+    ("az_get_states", _i, [_vp, _vp, _vp, _vp]),
+    ("az_clear", _i, [_vp, _i]),
+    ("az_clear_masked", _i, [_vp, _vp]),
+    ("az_set_active", _i, [_vp, _vp]),
+    ("az_set_noise_table", _i, [_vp, _vp, _i]),
+    ("az_simulate_fused", _i, [_vp, _i, _i, _f, _f, _ull, _vp]),
+    ("az_begin_simulate", _i, [_vp, _vp]),
+    ("az_select", _i, [_vp, _vp, _vp, _vp]),
+    ("az_expand_backup", _i, [_vp, _vp, _vp, _i, _vp]),
+    ("az_make_move", _i, [_vp, _vp, _i, _vp]),
+    ("az_make_movexy", _i, [_vp, _i, _i, _i]),
+    ("az_select_greedy", _i, [_vp, _vp, _vp]),
+    ("az_get_counts", _i, [_vp, _vp, _vp]),
+    ("az_get_prob", _i, [_vp, _i, _vp]),
+    ("az_get_board", _i, [_vp, _i, _vp]),
+    ("az_get_raw_board", _i, [_vp, _i, _vp]),
+    ("az_get_node", _i, [_vp, _i, _vp, _i, C.POINTER(_i), C.POINTER(_i), _vp, _vp, _vp]),
+    ("az_get_stats", _i, [_vp] + [C.POINTER(_ull)] * 4),
+    ("az_reset_stats", _i, [_vp]),
+    ("az_get_pool_usage", _i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
+    ("az_sync_check", _i, [_vp, _vp]),
+    ("az_timing_begin", _i, [_vp, _vp]),
+    ("az_timing_end", _i, [_vp, _vp, C.POINTER(_f)]),
+]
+
+_lib = None
+
+
+def load_library():
+    """Loads libazmcts.so; raises if it has not been built (no CPU fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C alphazero_amd/csrc` "
+                "(or __graft_entry__.build()); the engine has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class EngineError(RuntimeError):
+    """Failure reported by the C ABI; `.code` is the AZ_ERR_* value."""
+
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    return int(x)
+
+
+class Engine:
+    def __init__(self, n_trees, shape, nodes_per_tree=2048, alpha=1.0, cpuct=1.0, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.az_create(C.byref(h), device, n_trees, shape, nodes_per_tree, alpha, cpuct)
+        self.h = h if rc == 0 else None
+        self._check(rc)
+        self.n_trees, self.shape, self.size = n_trees, shape, shape * shape
+        self.device = device
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(rc, self.L.az_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.az_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters (cmcts.cpp:46-81)
+    def set_eps(self, v): self._check(self.L.az_set_eps(self.h, v))
+    def get_eps(self): return self.L.az_get_eps(self.h)
+    def set_cpuct(self, v): self._check(self.L.az_set_cpuct(self.h, v))
+    def get_cpuct(self): return self.L.az_get_cpuct(self.h)
+    def set_alpha(self, v): self._check(self.L.az_set_alpha(self.h, v))
+    def get_alpha(self): return self.L.az_get_alpha(self.h)
+    def set_alpha_default(self): self._check(self.L.az_set_alpha_default(self.h))
+    def set_threads(self, v): self._check(self.L.az_set_threads(self.h, v))
+    def get_threads(self): return self.L.az_get_threads(self.h)
+    def set_cuda(self, v): self._check(self.L.az_set_cuda(self.h, v))
+    def get_cuda(self): return self.L.az_get_cuda(self.h)
+    def device_bytes(self): return self.L.az_device_bytes(self.h)
+
+    # ---- per-tree state
+    def set_player(self, tree, player): self._check(self.L.az_set_player(self.h, tree, player))
+
+    def get_state(self, tree):
+        p, m, w = C.c_int(), C.c_int(), C.c_float()
+        self._check(self.L.az_get_state(self.h, tree, C.byref(p), C.byref(m), C.byref(w)))
+        return p.value, m.value, w.value
+
+    def get_states(self):
+        p = np.empty(self.n_trees, np.int32)
+        m = np.empty(self.n_trees, np.int32)
+        w = np.empty(self.n_trees, np.float32)
+        self._check(self.L.az_get_states(self.h, _ptr(p), _ptr(m), _ptr(w)))
+        return p, m, w
+
+    def clear(self, tree=-1): self._check(self.L.az_clear(self.h, tree))
+
+    def clear_masked(self, mask):
+        mask = np.ascontiguousarray(mask, np.uint8)
+        assert mask.shape == (self.n_trees,)
+        self._check(self.L.az_clear_masked(self.h, _ptr(mask)))
+
+    def set_active(self, mask=None):
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, np.uint8)
+            assert mask.shape == (self.n_trees,)
+        self._check(self.L.az_set_active(self.h, _ptr(mask)))
+
+    def set_noise_table(self, noise):
+        if noise is None:
+            self._check(self.L.az_set_noise_table(self.h, None, 0))
+            return
+        noise = np.ascontiguousarray(noise, np.float64)
+        assert noise.ndim == 2 and noise.shape[1] == self.size
+        self._check(self.L.az_set_noise_table(self.h, _ptr(noise), noise.shape[0]))
+
+    # ---- search
+    def simulate_fused(self, n, eval_kind=EVAL_UNIFORM, const_prior=0.0, const_value=0.0, hash_seed=0,
+                       stream=None, sync=True):
+        self._check(self.L.az_simulate_fused(self.h, n, eval_kind, const_prior, const_value, hash_seed, stream))
+        if sync:
+            self.sync_check(stream)
+
+    def begin_simulate(self, stream=None): self._check(self.L.az_begin_simulate(self.h, stream))
+
+    def select(self, d_boards, d_leaf_kind, stream=None):
+        self._check(self.L.az_select(self.h, _ptr(d_boards), _ptr(d_leaf_kind), stream))
+
+    def expand_backup(self, d_value, d_prior, prior_is_log, stream=None):
+        self._check(self.L.az_expand_backup(self.h, _ptr(d_value), _ptr(d_prior), int(prior_is_log), stream))
+
+    def make_move(self, actions, stream=None):
+        actions = np.ascontiguousarray(actions, np.int32)
+        assert actions.shape == (self.n_trees,)
+        self._check(self.L.az_make_move(self.h, _ptr(actions), 0, stream))
+
+    def make_move_device(self, d_actions, stream=None):
+        self._check(self.L.az_make_move(self.h, _ptr(d_actions), 1, stream))
+
+    def make_movexy(self, tree, x, y): self._check(self.L.az_make_movexy(self.h, tree, x, y))
+
+    def select_greedy(self, d_actions, stream=None):
+        self._check(self.L.az_select_greedy(self.h, _ptr(d_actions), stream))
+
+    def sync_check(self, stream=None): self._check(self.L.az_sync_check(self.h, stream))
+
+    # ---- results
+    def get_counts(self):
+        counts = np.empty((self.n_trees, self.size), np.int32)
+        root_n = np.empty(self.n_trees, np.int32)
+        self._check(self.L.az_get_counts(self.h, _ptr(counts), _ptr(root_n)))
+        return counts, root_n
+
+    def get_prob(self, tree):
+        out = np.empty(self.size, np.float32)
+        self._check(self.L.az_get_prob(self.h, tree, _ptr(out)))
+        return out
+
+    def get_board(self, tree):
+        out = np.empty((2, self.shape, self.shape), np.float32)
+        self._check(self.L.az_get_board(self.h, tree, _ptr(out)))
+        return out
+
+    def get_raw_board(self, tree):
+        out = np.empty((2, self.shape, self.shape), np.int8)
+        self._check(self.L.az_get_raw_board(self.h, tree, _ptr(out)))
+        return out
+
+    def get_node(self, tree, path):
+        path = np.ascontiguousarray(path, np.int32)
+        found, node_n = C.c_int(), C.c_int()
+        counts = np.empty(self.size, np.int32)
+        w = np.empty(self.size, np.float64)
+        p = np.empty(self.size, np.float64)
+        self._check(self.L.az_get_node(self.h, tree, _ptr(path) if len(path) else None, len(path),
+                                       C.byref(found), C.byref(node_n), _ptr(counts), _ptr(w), _ptr(p)))
+        if not found.value:
+            return None
+        return node_n.value, counts, w, p
+
+    def get_stats(self):
+        v = [C.c_ulonglong() for _ in range(4)]
+        self._check(self.L.az_get_stats(self.h, *[C.byref(x) for x in v]))
+        return dict(sims=v[0].value, expansions=v[1].value, terminals=v[2].value, select_calls=v[3].value)
+
+    def reset_stats(self): self._check(self.L.az_reset_stats(self.h))
+
+    def pool_usage(self, tree=0):
+        u, m = C.c_int(), C.c_int()
+        self._check(self.L.az_get_pool_usage(self.h, tree, C.byref(u), C.byref(m)))
+        return u.value, m.value
+
+    def timing_begin(self, stream=None): self._check(self.L.az_timing_begin(self.h, stream))
+
+    def timing_end(self, stream=None):
+        ms = C.c_float()
+        self._check(self.L.az_timing_end(self.h, stream, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,194 @@
+/*
+ * azmcts.h -- C ABI of the MI355X batched MCTS engine (libazmcts.so).
+ *
+ * One engine holds `n_trees` independent gomoku search trees (one reference
+ * `cmcts.mcts` object each) as structure-of-arrays node pools in HBM of ONE
+ * GPU.  Every entry point takes plain pointers and sizes; pointers named
+ * `d_*` are device addresses on the engine's GPU, all others are host memory.
+ * `stream` arguments are a hipStream_t passed as void* (NULL = default stream).
+ *
+ * Each function cites the reference interface it replaces
+ * (paths relative to the reference repository root).
+ *
+ * Return value: 0 on success, an AZ_ERR_* code otherwise; az_last_error()
+ * returns the message for the calling thread, worded like the reference's
+ * std::runtime_error texts so a Python facade can raise RuntimeError with it.
+ */
+#ifndef AZMCTS_H
+#define AZMCTS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct az_engine az_engine;
+
+enum {
+    AZ_OK = 0,
+    AZ_ERR_INVALID_MOVE  = 1,  /* mcts/src/state.cpp:85-86   "Invalid move"                  */
+    AZ_ERR_BAD_SIMS      = 2,  /* mcts/src/cmcts.cpp:86-87   "Invalid input n must be >= 1"  */
+    AZ_ERR_NOT_DIST      = 3,  /* mcts/src/cmcts.cpp:336-339 "Not a distribution"            */
+    AZ_ERR_EPS_RANGE     = 4,  /* mcts/src/cmcts.cpp:52-53   "Epsilon must be in range <0,1>"*/
+    AZ_ERR_BAD_XY        = 5,  /* mcts/src/cmcts.cpp:299-300 "Invalid index y.. or x.."      */
+    AZ_ERR_NO_ACTION     = 6,  /* mcts/src/node.cpp:115      childN.at(-1) / "No action chosen" */
+    AZ_ERR_NOISE_ROWS    = 7,  /* engine: noise table shorter than the expansions of a call  */
+    AZ_ERR_INVALID_VALUE = 8,  /* mcts/src/cmcts.cpp:70      "Invalid value"                 */
+    AZ_ERR_NO_PREDICTOR  = 9,  /* mcts/src/cmcts.cpp:89-91   "Predictor missing!"            */
+    AZ_ERR_POOL_FULL     = 10, /* engine: a tree ran out of node-pool slots                  */
+    AZ_ERR_ARG           = 11, /* engine: bad argument (shape, tree index, null pointer)     */
+    AZ_ERR_HIP           = 12, /* engine: a HIP runtime call failed                          */
+    AZ_ERR_STATE         = 13  /* engine: call sequence violated (expand without select ...) */
+};
+
+/* evaluator kinds of az_simulate_fused (test / isolation evaluators computed
+ * inside the kernel; a neural net goes through az_select + az_expand_backup) */
+enum {
+    AZ_EVAL_UNIFORM = 0, /* prior = const_prior everywhere, value = const_value        */
+    AZ_EVAL_HASH    = 1  /* integer hash of the two bit planes, exact in fp32          */
+};
+
+/* leaf kinds written by az_select */
+enum {
+    AZ_LEAF_NONE     = 0, /* tree inactive or in error: no work this step              */
+    AZ_LEAF_EXPAND   = 1, /* needs (value, priors) for the board written to d_boards   */
+    AZ_LEAF_TERMINAL = 2  /* search ended on a finished game: no evaluation needed     */
+};
+
+const char *az_last_error(void);
+
+/* replaces the module-level functions of mcts/src/module.cpp:6-16 */
+const char *az_version(void);          /* module.cpp:15  version()          */
+const char *az_build_timestamp(void);  /* module.cpp:16  build_timestamp()  */
+
+/* Cmcts::Cmcts (mcts/src/cmcts.cpp:5-21), for n_trees objects at once.
+ * shape: board edge (5..20; the reference's -DSHAPE macro, mcts/CMakeLists.txt:36).
+ * nodes_per_tree: node-pool slots per tree (each slot holds the dense child
+ * statistics of one position).  alpha/cpuct as in the reference constructor;
+ * eps starts at 0.25 and threads at 0 like cmcts.cpp:8-9. */
+int az_create(az_engine **out, int device, int n_trees, int shape, int nodes_per_tree,
+              double alpha, double cpuct);
+/* Cmcts::~Cmcts (cmcts.cpp:23-28) */
+void az_destroy(az_engine *e);
+
+int az_n_trees(const az_engine *e);
+int az_shape(const az_engine *e);
+int az_nodes_per_tree(const az_engine *e);
+/* bytes of HBM the engine allocated */
+unsigned long long az_device_bytes(const az_engine *e);
+
+/* setters / getters: mcts/src/cmcts.cpp:46-81 (module.cpp:19-58).  They apply
+ * to every tree of the engine. */
+int    az_set_eps(az_engine *e, double eps);          /* cmcts.cpp:51-55, range-checked */
+double az_get_eps(const az_engine *e);
+int    az_set_cpuct(az_engine *e, float cpuct);       /* cmcts.cpp:58 (float in, double stored) */
+float  az_get_cpuct(const az_engine *e);              /* cmcts.cpp:57 */
+int    az_set_alpha(az_engine *e, double alpha);      /* cmcts.cpp:64 */
+double az_get_alpha(const az_engine *e);              /* cmcts.cpp:63 */
+int    az_set_alpha_default(az_engine *e);            /* cmcts.cpp:75-81 */
+int    az_set_threads(az_engine *e, int threads);     /* cmcts.cpp:61 */
+int    az_get_threads(const az_engine *e);
+int    az_set_cuda(az_engine *e, int cuda);           /* cmcts.cpp:70: always fails, like the reference */
+int    az_get_cuda(const az_engine *e);               /* cmcts.cpp:69 */
+
+/* per-tree state: cmcts.cpp:47-48,72-73 */
+int az_set_player(az_engine *e, int tree, int player);
+int az_get_state(az_engine *e, int tree, int *player, int *move_cnt, float *winner);
+/* all trees at once (host arrays of n_trees; any may be NULL) */
+int az_get_states(az_engine *e, int *player, int *move_cnt, float *winner);
+
+/* Cmcts::clear (cmcts.cpp:30-37) for one tree (tree >= 0) or all (tree < 0) */
+int az_clear(az_engine *e, int tree);
+/* clear the trees whose mask byte is non-zero (host array of n_trees) */
+int az_clear_masked(az_engine *e, const unsigned char *mask);
+
+/* which trees take part in simulate / select (host array of n_trees bytes;
+ * NULL = all).  Trees left out keep their state untouched. */
+int az_set_active(az_engine *e, const unsigned char *mask);
+
+/* Dirichlet noise as an input table: rows x SIZE doubles, row-major, host
+ * memory.  Row k is mixed into the k-th expansion of a simulate() call of a
+ * tree -- the reference re-creates a default-seeded generator per call
+ * (cmcts.cpp:132-133), so every call replays the same stream.  rows = 0 removes
+ * the table (then eps must be 0).  Replaces gsl_ran_dirichlet at node.cpp:38. */
+int az_set_noise_table(az_engine *e, const double *noise, int rows);
+
+/* Cmcts::simulate (cmcts.cpp:83-125) with the evaluator computed in-kernel:
+ * n searches on every active tree, whole call in one launch.  Thread fan-out
+ * rounding of cmcts.cpp:98-107 is applied when threads > 1 (workers run one
+ * after another, each restarting the noise stream). */
+int az_simulate_fused(az_engine *e, int n, int eval_kind, float const_prior, float const_value,
+                      unsigned long long hash_seed, void *stream);
+
+/* One search step for an external evaluator (the batched policy/value net):
+ *   az_begin_simulate        once per simulate() call: restarts the noise stream
+ *   az_select                Cmcts::search up to the leaf (cmcts.cpp:189-268):
+ *                            writes, per tree, the leaf kind and the raw
+ *                            un-swapped board as float [n_trees][2][S][S]
+ *                            (the tensor of cmcts.cpp:206-210) to device memory
+ *   az_expand_backup         set_prior + backup (node.cpp:26-47, cmcts.cpp:228-279):
+ *                            d_value  float [n_trees]  (net output, not negated)
+ *                            d_prior  float [n_trees][SIZE]; log-probabilities
+ *                            if prior_is_log (expf applied, node.cpp:42), else
+ *                            linear probabilities */
+int az_begin_simulate(az_engine *e, void *stream);
+int az_select(az_engine *e, float *d_boards, int *d_leaf_kind, void *stream);
+int az_expand_backup(az_engine *e, const float *d_value, const float *d_prior, int prior_is_log,
+                     void *stream);
+
+/* Cmcts::make_move (cmcts.cpp:284-294) on every tree with action >= 0
+ * (action < 0 = leave the tree alone).  `actions` is a host array unless
+ * on_device.  Illegal moves change nothing; with a host array the call fails
+ * with AZ_ERR_INVALID_MOVE naming the first offending tree. */
+int az_make_move(az_engine *e, const int *actions, int on_device, void *stream);
+/* Cmcts::make_movexy (cmcts.cpp:296-309) on one tree */
+int az_make_movexy(az_engine *e, int tree, int x, int y);
+
+/* argmax of the root visit counts of every tree, first maximum wins (what
+ * `pi.argmax()` picks at src/eval.py:192, src/self_play.py:160); -1 for
+ * inactive trees.  Result stays on the device for az_make_move(on_device=1). */
+int az_select_greedy(az_engine *e, int *d_actions, void *stream);
+
+/* root statistics of every tree: counts int32 [n_trees][SIZE] (Node::counts,
+ * node.cpp:160-164), root_n int32 [n_trees] (Node::nodeN; -1 = unexpanded).
+ * Host arrays; any may be NULL. */
+int az_get_counts(az_engine *e, int *counts, int *root_n);
+/* Cmcts::get_prob (cmcts.cpp:317-341) for one tree: float32[SIZE]; fails with
+ * AZ_ERR_NOT_DIST exactly when the reference throws. */
+int az_get_prob(az_engine *e, int tree, float *prob);
+/* State::get_board (state.cpp:39-48): float32 [2][S][S], planes swapped when
+ * player == 1 so plane 0 is the side to move. */
+int az_get_board(az_engine *e, int tree, float *board);
+/* raw planes as the evaluator sees them (cmcts.cpp:206-210): int8 [2][S][S] */
+int az_get_raw_board(az_engine *e, int tree, signed char *board);
+
+/* introspection for parity tests and print_node (cmcts.cpp:404-417): walks from
+ * the root of `tree` along path[0..len).  Returns AZ_OK and fills node_n,
+ * counts[SIZE], w[SIZE], p[SIZE] (any may be NULL), or sets *found = 0 when a
+ * link on the way is null (Node::is_null, node.cpp:136-145). */
+int az_get_node(az_engine *e, int tree, const int *path, int len, int *found, int *node_n,
+                int *counts, double *w, double *p);
+
+/* counters since creation / last az_reset_stats, summed over trees:
+ * simulations, expansions, terminal hits, select calls (the quantities the
+ * reference's unused Stats header names, mcts/src/stats.h:6-25).  Any NULL. */
+int az_get_stats(az_engine *e, unsigned long long *sims, unsigned long long *expansions,
+                 unsigned long long *terminals, unsigned long long *select_calls);
+int az_reset_stats(az_engine *e);
+/* live node-pool slots of one tree, and the maximum over all trees */
+int az_get_pool_usage(az_engine *e, int tree, int *used, int *max_used);
+
+/* waits for the engine's outstanding work on `stream` and reports the first
+ * per-tree error raised inside a kernel (AZ_ERR_POOL_FULL, AZ_ERR_NO_ACTION,
+ * AZ_ERR_NOISE_ROWS, AZ_ERR_INVALID_MOVE), clearing it. */
+int az_sync_check(az_engine *e, void *stream);
+
+/* HIP-event timing of the engine's own kernels on the stream they were
+ * launched on: az_timing_begin records, az_timing_end records + waits and
+ * returns elapsed milliseconds. */
+int az_timing_begin(az_engine *e, void *stream);
+int az_timing_end(az_engine *e, void *stream, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -72,6 +72,30 @@ SYMBOLS = [
 _lib = None
 
 
+def _load_hip_runtime():
+    """libazmcts.so carries no DT_NEEDED for the HIP runtime, so that it shares
+    the ONE runtime of the process.  PyTorch wheels bundle their own
+    libamdhip64.so; if torch is installed that copy is loaded (whether or not
+    torch has been imported yet), else the system ROCm one."""
+    import importlib.util
+
+    candidates = []
+    spec = importlib.util.find_spec("torch")
+    if spec is not None and spec.origin:
+        candidates.append(os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so"))
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    candidates += [os.path.join(rocm, "lib", "libamdhip64.so"), "libamdhip64.so"]
+    last = None
+    for path in candidates:
+        if os.path.isabs(path) and not os.path.exists(path):
+            continue
+        try:
+            return C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError as e:  # try the next candidate
+            last = e
+    raise ImportError(f"no HIP runtime (libamdhip64.so) could be loaded: {last}")
+
+
 def load_library():
     """Loads libazmcts.so; raises if it has not been built (no CPU fallback)."""
     global _lib
@@ -80,6 +104,7 @@ def load_library():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `make -C alphazero_amd/csrc` "
                 "(or __graft_entry__.build()); the engine has no CPU fallback")
+        _load_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)

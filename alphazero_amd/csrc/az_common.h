@@ -2,21 +2,28 @@
 //
 // Node pool (per GPU):  n_trees arenas of `cap` fixed-size records.
 //   record(tree t, slot i) at nodes + ((size_t)t * cap + i) * REC_BYTES, holding
-//   the dense child statistics of ONE position, lane-blocked: lane L of the
-//   wavefront that owns the tree works on actions [L*EPL, L*EPL+EPL), EPL =
-//   ceil(S*S/64), SP = 64*EPL padded actions:
+//   the dense child statistics of ONE position over SP padded actions (SP is a
+//   multiple of 64 fixed per board shape, see az_kernels.hip):
 //       N    int32  [SP]   visit counts          (Node::childN, node.h:46)
 //       LINK int32  [SP]   child slot + 1, 0=null (Node::child,  node.h:44)
 //       W    double [SP]   value sums            (Node::childW, node.h:47)
 //       P    double [SP]   priors                (Node::childP, node.h:37)
-//   node_n[t*cap+i]  int32: Node::nodeN (node.h:35) of an expanded node
+//   Actions are thread-blocked: a group of T threads working on a node gives
+//   thread t the actions [t*E, t*E+E), E = SP/T, so every array is read and
+//   written with contiguous, vector-width accesses.
+//   Node::nodeN (node.h:35) is not stored for inner nodes: a child reached
+//   through action a of its parent has nodeN = N_parent[a] - 1 (the first
+//   visit of the action expands the child, every later one selects from it);
+//   the root's nodeN lives in the tree header.
+//   N, LINK and W of a node are materialised lazily: while nodeN == 0 they are
+//   implicitly zero and only P is in memory; the first select on the node (or
+//   its promotion to root) writes them.
 //   parent[t*cap+i]  int32: parent slot, -1 for a root, -2 for a free slot
 //   free_stack[t*cap + k], k < free_top: free slots, popped from the top
 //   order[t*cap + k],  k < n_order: live slots in allocation order (a parent
 //                      always precedes its children), used by re-rooting
-// Per tree: AzTree header, plus the board twice in wave layout:
+// Per tree: AzTree header, plus the board as bitboards in wave layout:
 //   rows[t*64 + L]: bit c = stone at (row L&31, col c) of plane L>>5
-//   occ [t*64 + L]: bit k = action L*EPL+k occupied (either plane)
 #ifndef AZ_COMMON_H
 #define AZ_COMMON_H
 
@@ -24,10 +31,13 @@
 
 #define AZ_MAX_SHAPE 20
 // board edges compiled into the library (keep in step with SHAPES in the Makefile)
+#ifndef AZ_SHAPE_LIST
 #define AZ_SHAPE_LIST(X) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20)
+#endif
 
 struct AzTree {
     int root;        // slot of the root node, -1 while the root is unexpanded (nodeN == -1)
+    int root_n;      // Node::nodeN of the root (valid when root >= 0)
     int free_top;    // entries in this tree's free stack
     int n_order;     // live slots
     int player;      // 0/1 to move               (State::player,  state.h:42)
@@ -44,15 +54,14 @@ struct AzTree {
 
 struct AzParams {
     char *nodes;
-    int *node_n;
     int *parent;
     int *free_stack;
     int *order;
     AzTree *trees;
     unsigned *rows;
-    unsigned *occ;
     int *path_node;   // [n_trees][path_cap] slots along the pending path
     int *path_act;    // [n_trees][path_cap]
+    unsigned long long *stamps; // diagnostic builds only (AZ_STAMPS): [n_trees][8] cycle sums, else null
     const double *noise; // [noise_rows][SP] or null
     int noise_rows;
     int n_trees;
@@ -60,9 +69,11 @@ struct AzParams {
     int path_cap;
     double cpuct;
     double eps;
+    int no_screen;    // 1 = skip the fp32 screening pass of select (exact fp64 pass only)
 };
 
 struct AzFusedArgs {
+    int waves_per_tree;  // 0 = let the launcher choose from the number of trees
     int n_total;         // searches per tree in this launch
     int per_worker;      // noise stream restarts every per_worker searches
     int eval_kind;
@@ -75,6 +86,7 @@ struct AzFusedArgs {
 // with -DAZ_S=<shape>); the engine picks the table entry of its shape.
 struct AzShapeOps {
     int shape;
+    int sp;              // padded actions per node record of this shape
     int (*simulate_fused)(const AzParams &, const AzFusedArgs &, void *stream);
     int (*select)(const AzParams &, float *d_boards, int *d_leaf_kind, void *stream);
     int (*expand_backup)(const AzParams &, const float *d_value, const float *d_prior,

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -150,8 +151,8 @@ int az_create(az_engine **out, int device, int n_trees, int shape, int nodes_per
     e->n_trees = n_trees;
     e->shape = shape;
     e->size = shape * shape;
-    e->epl = (e->size + 63) / 64;
-    e->sp = 64 * e->epl;
+    e->sp = ops->sp;
+    e->epl = e->sp / 64;
     e->cap = nodes_per_tree;
     e->rec_bytes = (size_t)e->sp * 24;
     e->ops = ops;
@@ -164,22 +165,28 @@ int az_create(az_engine **out, int device, int n_trees, int shape, int nodes_per
     P.eps = 0.25; // cmcts.cpp:8
     P.noise = nullptr;
     P.noise_rows = 0;
+    P.stamps = nullptr;
+    // fp32 screening of the PUCT arg-max is off unless AZ_SCREEN=1: on MI355X the
+    // extra pass costs more instructions than the fp64 divisions it avoids
+    P.no_screen = 1;
+    if (const char *x = getenv("AZ_SCREEN")) P.no_screen = atoi(x) == 0;
     const size_t slots = (size_t)n_trees * nodes_per_tree;
     int rc = AZ_OK;
     if (!rc) rc = dev_alloc(e, &P.nodes, slots * e->rec_bytes);
-    if (!rc) rc = dev_alloc(e, &P.node_n, slots);
     if (!rc) rc = dev_alloc(e, &P.parent, slots);
     if (!rc) rc = dev_alloc(e, &P.free_stack, slots);
     if (!rc) rc = dev_alloc(e, &P.order, slots);
     if (!rc) rc = dev_alloc(e, &P.trees, (size_t)n_trees);
     if (!rc) rc = dev_alloc(e, &P.rows, (size_t)n_trees * 64);
-    if (!rc) rc = dev_alloc(e, &P.occ, (size_t)n_trees * 64);
     if (!rc) rc = dev_alloc(e, &P.path_node, (size_t)n_trees * P.path_cap);
     if (!rc) rc = dev_alloc(e, &P.path_act, (size_t)n_trees * P.path_cap);
     if (!rc) rc = dev_alloc(e, &e->d_actions, (size_t)n_trees);
     if (!rc) rc = dev_alloc(e, &e->d_mask, (size_t)n_trees);
     if (!rc) rc = dev_alloc(e, &e->d_counts, (size_t)n_trees * e->size);
     if (!rc) rc = dev_alloc(e, &e->d_root_n, (size_t)n_trees);
+#ifdef AZ_STAMPS
+    if (!rc) rc = dev_alloc(e, &P.stamps, (size_t)n_trees * 8);
+#endif
     if (rc) { az_destroy(e); return rc; }
 
     // initial pool state: every slot free, stack pops 0,1,2,...
@@ -190,10 +197,10 @@ int az_create(az_engine **out, int device, int n_trees, int shape, int nodes_per
         hipError_t he = hipMemcpy(P.free_stack, stack.data(), slots * sizeof(int), hipMemcpyHostToDevice);
         if (he == hipSuccess) he = hipMemcpy(P.parent, par.data(), slots * sizeof(int), hipMemcpyHostToDevice);
         if (he == hipSuccess) he = hipMemset(P.rows, 0, (size_t)n_trees * 64 * sizeof(unsigned));
-        if (he == hipSuccess) he = hipMemset(P.occ, 0, (size_t)n_trees * 64 * sizeof(unsigned));
         e->h_trees.assign(n_trees, AzTree{});
         for (auto &t : e->h_trees) {
             t.root = -1;
+            t.root_n = -1;
             t.free_top = nodes_per_tree;
             t.winner = -1.f;
             t.active = 1;
@@ -217,8 +224,8 @@ void az_destroy(az_engine *e)
     DeviceGuard g(e->device);
     (void)hipDeviceSynchronize();
     AzParams &P = e->P;
-    void *ptrs[] = {P.nodes, P.node_n, P.parent, P.free_stack, P.order, P.trees, P.rows, P.occ,
-                    P.path_node, P.path_act, e->d_actions, e->d_mask, e->d_counts, e->d_root_n, e->d_noise};
+    void *ptrs[] = {P.nodes, P.parent, P.free_stack, P.order, P.trees, P.rows,
+                    P.path_node, P.path_act, P.stamps, e->d_actions, e->d_mask, e->d_counts, e->d_root_n, e->d_noise};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -394,6 +401,7 @@ int az_simulate_fused(az_engine *e, int n, int eval_kind, float const_prior, flo
         else if (n % th_num == 0) per = n / th_num;
         else per = n / th_num + 1;
     }
+    if (const char *w = getenv("AZ_WAVES_PER_TREE")) A.waves_per_tree = atoi(w); // tuning override
     A.n_total = th_num * per;
     A.per_worker = per;
     A.eval_kind = eval_kind;
@@ -506,14 +514,13 @@ int az_get_counts(az_engine *e, int *counts, int *root_n)
     return AZ_OK;
 }
 
-// reads one record's arrays of `tree`/`slot` into host vectors
-static int read_slot(az_engine *e, int tree, int slot, int *node_n, std::vector<int> *n, std::vector<int> *link,
+// reads one record's arrays of `tree`/`slot` into host vectors (the node must
+// be materialised, i.e. its nodeN > 0 or it is a root)
+static int read_slot(az_engine *e, int tree, int slot, std::vector<int> *n, std::vector<int> *link,
                      std::vector<double> *w, std::vector<double> *p)
 {
     const char *rec = e->P.nodes + ((size_t)tree * e->cap + slot) * e->rec_bytes;
     const int sp = e->sp;
-    if (node_n)
-        HIP_TRY(hipMemcpy(node_n, e->P.node_n + (size_t)tree * e->cap + slot, sizeof(int), hipMemcpyDeviceToHost));
     if (n) { n->resize(sp); HIP_TRY(hipMemcpy(n->data(), rec, sp * 4, hipMemcpyDeviceToHost)); }
     if (link) { link->resize(sp); HIP_TRY(hipMemcpy(link->data(), rec + (size_t)sp * 4, sp * 4, hipMemcpyDeviceToHost)); }
     if (w) { w->resize(sp); HIP_TRY(hipMemcpy(w->data(), rec + (size_t)sp * 8, sp * 8, hipMemcpyDeviceToHost)); }
@@ -531,8 +538,10 @@ int az_get_prob(az_engine *e, int tree, float *prob)
     HIP_TRY(hipMemcpy(&t, e->P.trees + tree, sizeof t, hipMemcpyDeviceToHost));
     std::vector<int> n(e->sp, 0);
     int node_n = -1; // unexpanded root (node.cpp:6)
-    if (t.root >= 0)
-        if (int rc = read_slot(e, tree, t.root, &node_n, &n, nullptr, nullptr, nullptr)) return rc;
+    if (t.root >= 0) {
+        node_n = t.root_n;
+        if (int rc = read_slot(e, tree, t.root, &n, nullptr, nullptr, nullptr)) return rc;
+    }
     // cmcts.cpp:323-339
     const double sum = (double)node_n;
     double prob_sum = 0;
@@ -587,20 +596,27 @@ int az_get_node(az_engine *e, int tree, const int *path, int len, int *found, in
     HIP_TRY(hipMemcpy(&t, e->P.trees + tree, sizeof t, hipMemcpyDeviceToHost));
     int slot = t.root;
     if (slot < 0) return AZ_OK;
+    int nn = t.root_n; // Node::nodeN of the node the walk stands on
     for (int i = 0; i < len; i++) {
         if (path[i] < 0 || path[i] >= e->size) return fail(AZ_ERR_ARG, "Index is out of bounds"); // node.cpp:139-140
-        int link = 0;
+        if (nn == 0 && i > 0) return AZ_OK; // never selected from: no children yet
+        int link = 0, cnt = 0;
         const char *rec = e->P.nodes + ((size_t)tree * e->cap + slot) * e->rec_bytes;
         HIP_TRY(hipMemcpy(&link, rec + (size_t)e->sp * 4 + (size_t)path[i] * 4, sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&cnt, rec + (size_t)path[i] * 4, sizeof(int), hipMemcpyDeviceToHost));
         if (link == 0) return AZ_OK;
         slot = link - 1;
+        nn = cnt - 1; // the first visit of the action created the child
     }
+    const bool fresh = nn == 0 && len > 0; // statistics not materialised yet: implicit zeros
     std::vector<int> n;
     std::vector<double> vw, vp;
-    if (int rc = read_slot(e, tree, slot, node_n, counts ? &n : nullptr, nullptr, w ? &vw : nullptr, p ? &vp : nullptr))
+    if (int rc = read_slot(e, tree, slot, (counts && !fresh) ? &n : nullptr, nullptr, (w && !fresh) ? &vw : nullptr,
+                           p ? &vp : nullptr))
         return rc;
-    if (counts) memcpy(counts, n.data(), sizeof(int) * e->size);
-    if (w) memcpy(w, vw.data(), sizeof(double) * e->size);
+    if (node_n) *node_n = nn;
+    if (counts) { if (fresh) memset(counts, 0, sizeof(int) * e->size); else memcpy(counts, n.data(), sizeof(int) * e->size); }
+    if (w) { if (fresh) memset(w, 0, sizeof(double) * e->size); else memcpy(w, vw.data(), sizeof(double) * e->size); }
     if (p) memcpy(p, vp.data(), sizeof(double) * e->size);
     *found = 1;
     return AZ_OK;
@@ -650,6 +666,18 @@ int az_get_pool_usage(az_engine *e, int tree, int *used, int *max_used)
     }
     return AZ_OK;
 }
+
+#ifdef AZ_STAMPS
+// diagnostic library only: per-tree phase cycle sums of the last fused launch
+int az_debug_stamps(az_engine *e, unsigned long long *out)
+{
+    if (!e || !out) return fail(AZ_ERR_ARG, "null argument");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, e->P.stamps, sizeof(unsigned long long) * 8 * e->n_trees, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+#endif
 
 int az_timing_begin(az_engine *e, void *stream)
 {

@@ -3,19 +3,26 @@
 // Compiled once per board shape with -DAZ_S=<shape>; every size below is a
 // compile-time constant of that translation unit.
 //
-// Execution model: ONE 64-lane wavefront owns ONE tree (workgroup = 1 wave,
-// grid = n_trees).  Lane L holds actions [L*EPL, L*EPL+EPL) of whatever node
-// the search stands on, so a node's statistics arrive with 16-byte vector
-// loads that are contiguous across the wave, PUCT is computed lane-parallel
-// and the arg-max is a DPP max-reduction plus one ballot.  Searches inside a
-// tree run strictly one after another (the reference's only deterministic
-// mode, threads <= 1, mcts/src/cmcts.cpp:120-122), parallelism comes from the
-// thousands of trees in flight.
+// Execution model: one workgroup owns one tree (grid = n_trees).  A group of
+// T = 64*WPT threads (WPT wavefronts) gives thread t the actions
+// [t*E, t*E+E) of whatever node the search stands on, E = SP/T, so a node's
+// statistics arrive with contiguous vector loads, PUCT is computed
+// thread-parallel and the arg-max is a DPP max-reduction per wavefront, one
+// ballot, and (WPT > 1) one LDS exchange + barrier across the wavefronts.
+// Searches inside a tree run strictly one after another (the reference's only
+// deterministic mode, threads <= 1, mcts/src/cmcts.cpp:120-122); parallelism
+// comes from the trees in flight, and splitting a tree over several wavefronts
+// lets each SIMD interleave several trees so node-pool latency is hidden.
 //
 // Arithmetic contract (bit-exact against the reference, mcts/src/node.cpp):
 // fp64 throughout, IEEE division and square root, NO fused multiply-add
 // (-ffp-contract=off plus the pragma below), operation order as written in
 // node.cpp:105-108, strict '>' arg-max so the lowest action index wins ties.
+//
+// Memory discipline inside a launch: every global word is only ever written
+// and later re-read by the SAME thread (the owner of that action), so no
+// fence or cross-wavefront visibility is needed; wavefronts exchange data
+// through LDS and s_barrier only.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -32,8 +39,10 @@ namespace {
 
 constexpr int S = AZ_S;
 constexpr int SIZE = S * S;
-constexpr int EPL = (SIZE + 63) / 64; // actions per lane
-constexpr int SP = 64 * EPL;          // padded actions per node
+constexpr int E4 = (SIZE + 255) / 256;                 // actions per thread at the widest group
+constexpr int WPT_MAX = (SIZE + 64 * E4 - 1) / (64 * E4); // wavefronts of the widest group (<= 4)
+constexpr int SP = WPT_MAX * 64 * E4;                  // padded actions per node
+constexpr int EPL = SP / 64;                           // actions per lane for one-wavefront kernels
 constexpr int REC_BYTES = SP * 24;
 constexpr int OFF_N = 0;
 constexpr int OFF_LINK = SP * 4;
@@ -42,21 +51,38 @@ constexpr int OFF_P = SP * 16;
 constexpr int PATH_CAP = SIZE + 1;
 
 static_assert(S >= 5 && S <= AZ_MAX_SHAPE, "shape out of range");
-static_assert(EPL >= 1 && EPL <= 8, "EPL");
+static_assert(WPT_MAX >= 1 && WPT_MAX <= 4 && EPL <= 8, "geometry");
 
-struct NodeRegs {
-    int n[EPL];
-    int link[EPL];
-    double w[EPL];
-    double p[EPL];
+template <int E> struct NodeRegs {
+    int n[E];
+    int link[E];
+    double w[E];
+    double p[E];
 };
 
 struct WState {
-    unsigned rb;   // lane L: row (L&31) of plane (L>>5)
-    unsigned occ;  // lane L: bit k = action L*EPL+k occupied
-    int player;    // wave-uniform
-    int move_cnt;  // wave-uniform
-    float winner;  // wave-uniform
+    unsigned rb;   // lane L of EVERY wavefront: row (L&31) of plane (L>>5)
+    unsigned occ;  // thread t: bit k = action t*E+k occupied
+    int player;    // uniform
+    int move_cnt;  // uniform
+    float winner;  // uniform
+};
+
+// outcome of one select: the chosen action and that action's statistics
+struct Pick {
+    int a;      // -1: no legal action with u > -inf
+    int n;      // N[a] before the increment
+    int link;   // LINK[a]
+    double w;   // W[a] before the virtual loss
+};
+
+struct Slot { // LDS exchange record of one wavefront
+    double m;
+    double w;
+    int a;
+    int n;
+    int link;
+    int pad;
 };
 
 // ---------------------------------------------------------------- utilities
@@ -117,85 +143,92 @@ __device__ __forceinline__ char *rec_ptr(const AzParams &P, int tree, int slot)
     return P.nodes + ((size_t)tree * P.cap + slot) * REC_BYTES;
 }
 
-// lane-blocked vector loads / stores of one per-action array of a record
-__device__ __forceinline__ void ld_i32(const char *base, int lane, int (&out)[EPL])
+// thread-blocked vector loads / stores of one per-action array of a record
+template <int E> __device__ __forceinline__ void ld_i32(const char *base, int tid, int (&out)[E])
 {
-    const int *p = reinterpret_cast<const int *>(base) + lane * EPL;
-    if constexpr (EPL % 4 == 0) {
+    const int *p = reinterpret_cast<const int *>(base) + tid * E;
+    if constexpr (E % 4 == 0) {
 #pragma unroll
-        for (int j = 0; j < EPL / 4; j++) {
+        for (int j = 0; j < E / 4; j++) {
             int4 v = reinterpret_cast<const int4 *>(p)[j];
             out[4 * j] = v.x; out[4 * j + 1] = v.y; out[4 * j + 2] = v.z; out[4 * j + 3] = v.w;
         }
-    } else if constexpr (EPL % 2 == 0) {
+    } else if constexpr (E % 2 == 0) {
 #pragma unroll
-        for (int j = 0; j < EPL / 2; j++) {
+        for (int j = 0; j < E / 2; j++) {
             int2 v = reinterpret_cast<const int2 *>(p)[j];
             out[2 * j] = v.x; out[2 * j + 1] = v.y;
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < EPL; j++) out[j] = p[j];
+        for (int j = 0; j < E; j++) out[j] = p[j];
     }
 }
-__device__ __forceinline__ void st_i32(char *base, int lane, const int (&in)[EPL])
+template <int E> __device__ __forceinline__ void st_i32(char *base, int tid, const int (&in)[E])
 {
-    int *p = reinterpret_cast<int *>(base) + lane * EPL;
-    if constexpr (EPL % 4 == 0) {
+    int *p = reinterpret_cast<int *>(base) + tid * E;
+    if constexpr (E % 4 == 0) {
 #pragma unroll
-        for (int j = 0; j < EPL / 4; j++)
+        for (int j = 0; j < E / 4; j++)
             reinterpret_cast<int4 *>(p)[j] = make_int4(in[4 * j], in[4 * j + 1], in[4 * j + 2], in[4 * j + 3]);
-    } else if constexpr (EPL % 2 == 0) {
+    } else if constexpr (E % 2 == 0) {
 #pragma unroll
-        for (int j = 0; j < EPL / 2; j++)
+        for (int j = 0; j < E / 2; j++)
             reinterpret_cast<int2 *>(p)[j] = make_int2(in[2 * j], in[2 * j + 1]);
     } else {
 #pragma unroll
-        for (int j = 0; j < EPL; j++) p[j] = in[j];
+        for (int j = 0; j < E; j++) p[j] = in[j];
     }
 }
-__device__ __forceinline__ void ld_f64(const char *base, int lane, double (&out)[EPL])
+template <int E> __device__ __forceinline__ void ld_f64(const char *base, int tid, double (&out)[E])
 {
-    const double *p = reinterpret_cast<const double *>(base) + lane * EPL;
-    if constexpr (EPL % 2 == 0) {
+    const double *p = reinterpret_cast<const double *>(base) + tid * E;
+    if constexpr (E % 2 == 0) {
 #pragma unroll
-        for (int j = 0; j < EPL / 2; j++) {
+        for (int j = 0; j < E / 2; j++) {
             double2 v = reinterpret_cast<const double2 *>(p)[j];
             out[2 * j] = v.x; out[2 * j + 1] = v.y;
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < EPL; j++) out[j] = p[j];
+        for (int j = 0; j < E; j++) out[j] = p[j];
     }
 }
-__device__ __forceinline__ void st_f64(char *base, int lane, const double (&in)[EPL])
+template <int E> __device__ __forceinline__ void st_f64(char *base, int tid, const double (&in)[E])
 {
-    double *p = reinterpret_cast<double *>(base) + lane * EPL;
-    if constexpr (EPL % 2 == 0) {
+    double *p = reinterpret_cast<double *>(base) + tid * E;
+    if constexpr (E % 2 == 0) {
 #pragma unroll
-        for (int j = 0; j < EPL / 2; j++)
+        for (int j = 0; j < E / 2; j++)
             reinterpret_cast<double2 *>(p)[j] = make_double2(in[2 * j], in[2 * j + 1]);
     } else {
 #pragma unroll
-        for (int j = 0; j < EPL; j++) p[j] = in[j];
+        for (int j = 0; j < E; j++) p[j] = in[j];
     }
 }
 
-__device__ __forceinline__ void load_node(const AzParams &P, int tree, int slot, int lane, NodeRegs &nd)
+// node with nodeN > 0: all four arrays; fresh node (nodeN == 0): only P exists
+template <int E>
+__device__ __forceinline__ void load_node(const AzParams &P, int tree, int slot, int tid, bool fresh, NodeRegs<E> &nd)
 {
     const char *rec = rec_ptr(P, tree, slot);
-    ld_i32(rec + OFF_N, lane, nd.n);
-    ld_i32(rec + OFF_LINK, lane, nd.link);
-    ld_f64(rec + OFF_W, lane, nd.w);
-    ld_f64(rec + OFF_P, lane, nd.p);
+    ld_f64<E>(rec + OFF_P, tid, nd.p);
+    if (fresh) {
+#pragma unroll
+        for (int k = 0; k < E; k++) { nd.n[k] = 0; nd.link[k] = 0; nd.w[k] = 0.; }
+    } else {
+        ld_i32<E>(rec + OFF_N, tid, nd.n);
+        ld_i32<E>(rec + OFF_LINK, tid, nd.link);
+        ld_f64<E>(rec + OFF_W, tid, nd.w);
+    }
 }
-__device__ __forceinline__ void store_node(const AzParams &P, int tree, int slot, int lane, const NodeRegs &nd)
+template <int E>
+__device__ __forceinline__ void store_stats(const AzParams &P, int tree, int slot, int tid, const NodeRegs<E> &nd)
 {
     char *rec = rec_ptr(P, tree, slot);
-    st_i32(rec + OFF_N, lane, nd.n);
-    st_i32(rec + OFF_LINK, lane, nd.link);
-    st_f64(rec + OFF_W, lane, nd.w);
-    st_f64(rec + OFF_P, lane, nd.p);
+    st_i32<E>(rec + OFF_N, tid, nd.n);
+    st_i32<E>(rec + OFF_LINK, tid, nd.link);
+    st_f64<E>(rec + OFF_W, tid, nd.w);
 }
 
 // ------------------------------------------------------------------- rules
@@ -243,22 +276,28 @@ __device__ __noinline__ int scan_order_winner(unsigned h, unsigned v, unsigned d
 }
 
 // State::make_move + State::is_end (mcts/src/state.cpp:81-110,152-272) on the
-// wave-resident bitboards.  `a` must be a legal, wave-uniform action.
-__device__ __forceinline__ void state_move(WState &s, int a, int lane)
+// wavefront-resident bitboards.  `a` must be a legal, uniform action.  Every
+// wavefront of a group keeps its own copy of the rows and runs this
+// identically, so no exchange is needed.
+template <int E> __device__ __forceinline__ void state_move(WState &s, int a, int tid)
 {
+    const int lane = tid & 63;
     const int r = a / S, c = a - r * S;
     if (lane == s.player * 32 + r) s.rb |= 1u << c;
-    if (lane == a / EPL) s.occ |= 1u << (a % EPL);
+    if (tid == a / E) s.occ |= 1u << (a % E);
     s.player = s.player ? 0 : 1; // state.cpp:89
     s.move_cnt += 1;
     if (s.move_cnt < 9) return;  // state.cpp:158-159
     // five-in-a-row windows anchored at this lane's row: bit c of
     //   h : (r,c..c+4)   v : (r..r+4,c)   d : (r+i,c+i)   an : (r+i,c-i)
+    // rows r+1..r+4 come from the next lanes: DPP wave_shl:1 (lane i reads lane
+    // i+1, lane 63 reads 0), four times; rows >= S are zero, so windows never
+    // leak from plane 0 into plane 1
     const unsigned r0 = s.rb;
-    const unsigned r1 = (unsigned)__shfl_down((int)r0, 1);
-    const unsigned r2 = (unsigned)__shfl_down((int)r0, 2);
-    const unsigned r3 = (unsigned)__shfl_down((int)r0, 3);
-    const unsigned r4 = (unsigned)__shfl_down((int)r0, 4);
+    const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)r0, 0x130, 0xF, 0xF, false);
+    const unsigned r2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)r1, 0x130, 0xF, 0xF, false);
+    const unsigned r3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)r2, 0x130, 0xF, 0xF, false);
+    const unsigned r4 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)r3, 0x130, 0xF, 0xF, false);
     const unsigned h = r0 & (r0 >> 1) & (r0 >> 2) & (r0 >> 3) & (r0 >> 4);
     const unsigned v = r0 & r1 & r2 & r3 & r4;
     const unsigned d = r0 & (r1 >> 1) & (r2 >> 2) & (r3 >> 3) & (r4 >> 4);
@@ -278,113 +317,23 @@ __device__ __forceinline__ void state_move(WState &s, int a, int lane)
     }
 }
 
-// ------------------------------------------------------------------ select
-// Node::select (mcts/src/node.cpp:85-124).  Returns the action (wave-uniform)
-// or -1 when no legal action has u > -inf; `wl`/`wk` = owning lane and slot.
-__device__ __forceinline__ int select_action(const NodeRegs &nd, int node_n, unsigned occ, double cpuct,
-                                             int lane, int &wl, int &wk)
-{
-    const double sq = __dsqrt_rn((double)node_n + 1e-8);
-    double best = -INFINITY;
-    int bk = -1;
-#pragma unroll
-    for (int k = 0; k < EPL; k++) {
-        const int a = lane * EPL + k;
-        const bool valid = (a < SIZE) && !((occ >> k) & 1u);
-        const double t = (cpuct * nd.p[k]) * sq;
-        double u = t;
-        if (nd.n[k] != 0)
-            u = nd.w[k] / (double)nd.n[k] + t / (double)(nd.n[k] + 1);
-        if (valid && u > best) {
-            best = u;
-            bk = k;
-        }
-    }
-    const double m = wave_max_f64(best);
-    const unsigned long long mask = __ballot(bk >= 0 && best == m);
-    if (mask == 0ull) return -1;
-    wl = __ffsll((long long)mask) - 1;
-    wk = lane_bcast_i32(bk, wl);
-    return wl * EPL + wk;
-}
-
-// ------------------------------------------------------ in-kernel evaluators
-__device__ __forceinline__ unsigned long long mix64(unsigned long long x)
-{
-    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
-    x ^= x >> 27; x *= 0x94d049bb133111ebull;
-    x ^= x >> 31;
-    return x;
-}
-
-// value (wave-uniform) and this lane's linear priors for the position `s`
-__device__ __forceinline__ float evaluate(const AzFusedArgs &A, const WState &s, int lane, float (&pr)[EPL])
-{
-    if (A.eval_kind == AZ_EVAL_UNIFORM) {
-#pragma unroll
-        for (int k = 0; k < EPL; k++) pr[k] = (lane * EPL + k < SIZE) ? A.const_prior : 0.f;
-        return A.const_value;
-    }
-    // hash evaluator: key = seed ^ XOR_rows mix64((plane*32+row+1) << 32 | rowbits)
-    unsigned long long hk = ((lane & 31) < S) ? mix64(((unsigned long long)(lane + 1) << 32) | s.rb) : 0ull;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) hk ^= (unsigned long long)__shfl_xor((long long)hk, o);
-    const unsigned long long key = A.hash_seed ^ hk;
-    const unsigned long long hv = mix64(key ^ 0x9e3779b97f4a7c15ull);
-    const float value = (float)((int)(hv & 0xFFFF) - 32768) / 32768.0f;
-#pragma unroll
-    for (int k = 0; k < EPL; k++) {
-        const int a = lane * EPL + k;
-        const unsigned long long hi = mix64(key + (unsigned long long)(a + 1) * 0x9e3779b97f4a7c15ull);
-        pr[k] = a < SIZE ? (float)((hi & 0xFFFF) + 1) * (1.0f / (65536.0f * 128.0f)) : 0.f;
-    }
-    return value;
-}
-
-// Node::set_prior (mcts/src/node.cpp:38-45): P = (1-eps)*prior + eps*noise.
-__device__ __forceinline__ void mix_prior(const AzParams &P, const float (&pr)[EPL], bool is_log,
-                                          int noise_row, int lane, double (&out)[EPL])
-{
-    const double prior_eps = 1. - P.eps;
-    double nz[EPL];
-#pragma unroll
-    for (int k = 0; k < EPL; k++) nz[k] = 0.;
-    if (P.noise != nullptr)
-        ld_f64(reinterpret_cast<const char *>(P.noise + (size_t)noise_row * SP), lane, nz);
-#pragma unroll
-    for (int k = 0; k < EPL; k++) {
-        const double p = is_log ? (double)expf(pr[k]) : (double)pr[k];
-        out[k] = (lane * EPL + k < SIZE) ? prior_eps * p + P.eps * nz[k] : 0.;
-    }
-}
-
-// writes a freshly expanded node: priors, zeroed statistics, nodeN = 0
-__device__ __forceinline__ void write_new_node(const AzParams &P, int tree, int slot, int parent_slot,
-                                               const double (&pp)[EPL], int lane)
-{
-    char *rec = rec_ptr(P, tree, slot);
-    int zi[EPL];
-    double zd[EPL];
-#pragma unroll
-    for (int k = 0; k < EPL; k++) { zi[k] = 0; zd[k] = 0.; }
-    st_i32(rec + OFF_N, lane, zi);
-    st_i32(rec + OFF_LINK, lane, zi);
-    st_f64(rec + OFF_W, lane, zd);
-    st_f64(rec + OFF_P, lane, pp);
-    if (lane == 0) {
-        P.node_n[(size_t)tree * P.cap + slot] = 0;
-        P.parent[(size_t)tree * P.cap + slot] = parent_slot;
-    }
-}
-
-__device__ __forceinline__ void load_state(const AzParams &P, int tree, int lane, WState &s)
+template <int E> __device__ __forceinline__ void load_state(const AzParams &P, int tree, int tid, WState &s)
 {
     const AzTree *T = &P.trees[tree];
+    const int lane = tid & 63;
     s.rb = P.rows[tree * 64 + lane];
-    s.occ = P.occ[tree * 64 + lane];
     s.player = uni(T->player);
     s.move_cnt = uni(T->move_cnt);
     s.winner = unif(T->winner);
+    // State::is_valid (state.cpp:29-37) for this thread's actions, from the rows
+    s.occ = 0u;
+#pragma unroll
+    for (int k = 0; k < E; k++) {
+        const int a = tid * E + k;
+        const int r = a < SIZE ? a / S : 0, c = a < SIZE ? a % S : 0;
+        const unsigned both = (unsigned)__shfl((int)s.rb, r) | (unsigned)__shfl((int)s.rb, 32 + r);
+        if (a < SIZE && ((both >> c) & 1u)) s.occ |= 1u << k;
+    }
 }
 
 // the raw, un-swapped planes as float [2][S][S] (the tensor of cmcts.cpp:206-210)
@@ -398,187 +347,515 @@ __device__ __forceinline__ void write_board(const WState &s, float *dst, int lan
     }
 }
 
+// ------------------------------------------------------------------ select
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+    v = fmaxf(v, __int_as_float(dpp_i32<0xB1>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i32<0x4E>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i32<0x141>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i32<0x140>(__float_as_int(v))));
+    const float r0 = __int_as_float(lane_bcast_i32(__float_as_int(v), 0));
+    const float r1 = __int_as_float(lane_bcast_i32(__float_as_int(v), 16));
+    const float r2 = __int_as_float(lane_bcast_i32(__float_as_int(v), 32));
+    const float r3 = __int_as_float(lane_bcast_i32(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+// Exact PUCT arg-max, Node::select (mcts/src/node.cpp:95-114), for the
+// elements of one wavefront: thread-local best in fp64, operation order as the
+// reference writes it.  Returns the wavefront maximum; (wl, wk) = owning lane
+// and element of the first maximum, wl = -1 if no legal action has u > -inf.
+template <int E>
+__device__ __forceinline__ double exact_argmax(const NodeRegs<E> &nd, int node_n, unsigned occ, double cpuct, int tid,
+                                               int &wl, int &wk)
+{
+    const double sq = __dsqrt_rn((double)node_n + 1e-8);
+    double best = -INFINITY;
+    int bk = -1;
+#pragma unroll
+    for (int k = 0; k < E; k++) {
+        const int a = tid * E + k;
+        const bool valid = (a < SIZE) && !((occ >> k) & 1u);
+        const double t = (cpuct * nd.p[k]) * sq;
+        double u = t;
+        if (nd.n[k] != 0)
+            u = nd.w[k] / (double)nd.n[k] + t / (double)(nd.n[k] + 1);
+        if (valid && u > best) {
+            best = u;
+            bk = k;
+        }
+    }
+    const double m = wave_max_f64(best);
+    const unsigned long long mask = __ballot(bk >= 0 && best == m);
+    wl = -1;
+    wk = 0;
+    if (mask != 0ull) {
+        wl = __ffsll((long long)mask) - 1;
+        wk = lane_bcast_i32(bk, wl);
+    }
+    return m;
+}
+
+// Screening pass in fp32.  Every element gets an approximation uf of its PUCT
+// value and a bound ef on |uf - u| (u = the reference's fp64 result):
+//   inputs rounded to fp32 (2^-24 each), v_rcp_f32 (1 ulp), v_sqrt_f32, and the
+//   fp32 products and sum give |uf - u| <= 11 * 2^-24 * (|Q| + |U|); the bound
+//   used is 32 * 2^-24 * (|Q| + |U|) plus 1e-36 for fp32 underflow.
+// With L = max(uf - ef) <= max u, an element with uf + ef < L cannot be the
+// arg-max (nor tie with it).  The survivors are resolved without fp64 when
+//   * there is exactly one, or
+//   * all of them have bit-identical (N, W, P): identical inputs give identical
+//     u, so the first one wins exactly as the reference's strict '>' scan;
+// otherwise, or when anything is not finite in fp32, the exact pass decides.
+// Returns true with (wl, wk) set when the screening decided.
+template <int E>
+__device__ __forceinline__ bool screened_argmax(const NodeRegs<E> &nd, int node_n, unsigned occ, double cpuct, int tid,
+                                                int &wl, int &wk)
+{
+    const float cf = (float)cpuct;
+    const float sf = __builtin_amdgcn_sqrtf((float)node_n + 1e-8f);
+    float up[E];
+    float lo = -INFINITY;
+    bool weird = false;
+#pragma unroll
+    for (int k = 0; k < E; k++) {
+        const int a = tid * E + k;
+        const bool valid = (a < SIZE) && !((occ >> k) & 1u);
+        const int n = nd.n[k];
+        const float tf = (cf * (float)nd.p[k]) * sf;
+        float uf = tf, mag = fabsf(tf);
+        if (n != 0) {
+            const float qf = (float)nd.w[k] * __builtin_amdgcn_rcpf((float)n);
+            const float e2 = tf * __builtin_amdgcn_rcpf((float)(n + 1));
+            uf = qf + e2;
+            mag = fabsf(qf) + fabsf(e2);
+        }
+        const float ef = mag * 0x1p-19f + 1e-36f;
+        weird |= valid && !(mag < INFINITY);
+        if (valid) lo = fmaxf(lo, uf - ef);
+        up[k] = valid ? uf + ef : -INFINITY;
+    }
+    if (__any(weird)) return false;
+    const float L = wave_max_f32(lo);
+    // candidates, in action order
+    int fk = E, ncand_lane = 0;
+#pragma unroll
+    for (int k = E - 1; k >= 0; k--)
+        if (up[k] >= L && up[k] > -INFINITY) { fk = k; ncand_lane++; }
+    const unsigned long long lanes = __ballot(fk < E);
+    if (lanes == 0ull) { wl = -1; wk = 0; return true; } // no legal action at all
+    wl = __ffsll((long long)lanes) - 1;
+    wk = lane_bcast_i32(fk, wl);
+    // one candidate in one lane: decided
+    const unsigned long long multi = __ballot(ncand_lane > 1);
+    if (multi == 0ull && (lanes & (lanes - 1)) == 0ull) return true;
+    // several: decided only if all carry the first one's exact inputs
+    int n0 = 0;
+    double w0 = 0., p0 = 0.;
+#pragma unroll
+    for (int k = 0; k < E; k++)
+        if (k == wk) { n0 = nd.n[k]; w0 = nd.w[k]; p0 = nd.p[k]; }
+    n0 = lane_bcast_i32(n0, wl);
+    const long long wb = __double_as_longlong(lane_bcast_f64(w0, wl));
+    const long long pb = __double_as_longlong(lane_bcast_f64(p0, wl));
+    bool differs = false;
+#pragma unroll
+    for (int k = 0; k < E; k++)
+        if (up[k] >= L && up[k] > -INFINITY)
+            differs |= nd.n[k] != n0 || __double_as_longlong(nd.w[k]) != wb || __double_as_longlong(nd.p[k]) != pb;
+    return !__any(differs);
+}
+
+// Node::select (mcts/src/node.cpp:85-124) over a group of WPT wavefronts.
+// `slots`/`phase`: double-buffered LDS exchange (unused when WPT == 1).
+template <int WPT, int E>
+__device__ __forceinline__ Pick select_pick(const NodeRegs<E> &nd, int node_n, unsigned occ, double cpuct, int tid,
+                                            Slot *slots, int &phase, bool screen = false)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    int wl = -1, wk = 0;
+    double m = 0.;
+    bool decided = false;
+    if constexpr (WPT == 1) {
+        if (screen) decided = screened_argmax<E>(nd, node_n, occ, cpuct, tid, wl, wk);
+    }
+    if (!decided) m = exact_argmax<E>(nd, node_n, occ, cpuct, tid, wl, wk);
+    Pick pk;
+    pk.a = -1; pk.n = 0; pk.link = 0; pk.w = 0.;
+    if (wl >= 0) {
+        int my_n = 0, my_link = 0;
+        double my_w = 0.;
+#pragma unroll
+        for (int k = 0; k < E; k++)
+            if (k == wk) { my_n = nd.n[k]; my_link = nd.link[k]; my_w = nd.w[k]; }
+        pk.a = (wave * 64 + wl) * E + wk;
+        pk.n = lane_bcast_i32(my_n, wl);
+        pk.link = lane_bcast_i32(my_link, wl);
+        pk.w = lane_bcast_f64(my_w, wl);
+    }
+    if constexpr (WPT == 1) {
+        return pk;
+    } else {
+        Slot *sl = slots + phase * WPT;
+        if (lane == 0) {
+            sl[wave].m = m; sl[wave].w = pk.w; sl[wave].a = pk.a; sl[wave].n = pk.n; sl[wave].link = pk.link;
+        }
+        __syncthreads();
+        Pick out;
+        out.a = -1; out.n = 0; out.link = 0; out.w = 0.;
+        double bm = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < WPT; w++) { // wavefront order = action order: first strict maximum wins
+            const int aw = sl[w].a;
+            const double mw = sl[w].m;
+            if (aw >= 0 && (out.a < 0 || mw > bm)) {
+                bm = mw; out.a = aw; out.n = sl[w].n; out.link = sl[w].link; out.w = sl[w].w;
+            }
+        }
+        phase ^= 1;
+        return out;
+    }
+}
+
+// ------------------------------------------------------ in-kernel evaluators
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x)
+{
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return x;
+}
+
+// value (uniform) and this thread's linear priors for the position `s`
+template <int E>
+__device__ __forceinline__ float evaluate(const AzFusedArgs &A, const WState &s, int tid, float (&pr)[E])
+{
+    if (A.eval_kind == AZ_EVAL_UNIFORM) {
+#pragma unroll
+        for (int k = 0; k < E; k++) pr[k] = (tid * E + k < SIZE) ? A.const_prior : 0.f;
+        return A.const_value;
+    }
+    // hash evaluator: key = seed ^ XOR_rows mix64((plane*32+row+1) << 32 | rowbits)
+    const int lane = tid & 63;
+    unsigned long long hk = ((lane & 31) < S) ? mix64(((unsigned long long)(lane + 1) << 32) | s.rb) : 0ull;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) hk ^= (unsigned long long)__shfl_xor((long long)hk, o);
+    const unsigned long long key = A.hash_seed ^ hk;
+    const unsigned long long hv = mix64(key ^ 0x9e3779b97f4a7c15ull);
+    const float value = (float)((int)(hv & 0xFFFF) - 32768) / 32768.0f;
+#pragma unroll
+    for (int k = 0; k < E; k++) {
+        const int a = tid * E + k;
+        const unsigned long long hi = mix64(key + (unsigned long long)(a + 1) * 0x9e3779b97f4a7c15ull);
+        pr[k] = a < SIZE ? (float)((hi & 0xFFFF) + 1) * (1.0f / (65536.0f * 128.0f)) : 0.f;
+    }
+    return value;
+}
+
+// Node::set_prior (mcts/src/node.cpp:38-45): P = (1-eps)*prior + eps*noise.
+template <int E>
+__device__ __forceinline__ void mix_prior(const AzParams &P, const float (&pr)[E], bool is_log, int noise_row,
+                                          int tid, double (&out)[E])
+{
+    const double prior_eps = 1. - P.eps;
+    double nz[E];
+#pragma unroll
+    for (int k = 0; k < E; k++) nz[k] = 0.;
+    if (P.noise != nullptr) {
+        ld_f64<E>(reinterpret_cast<const char *>(P.noise + (size_t)noise_row * SP), tid, nz);
+        // complete the load inside the branch: a wait placed after the merge would
+        // also run (as vmcnt(0), i.e. behind every earlier store) when there is no noise
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+#pragma unroll
+    for (int k = 0; k < E; k++) {
+        const double p = is_log ? (double)expf(pr[k]) : (double)pr[k];
+        out[k] = (tid * E + k < SIZE) ? prior_eps * p + P.eps * nz[k] : 0.;
+    }
+}
+
+// Path of the running search: entry d lives in lane d of four vector registers
+// (lane-select write, v_readlane with a scalar index), entries beyond 64 spill to LDS.
+struct PathRegs {
+    int node, act, w_lo, w_hi;
+};
+// d < 64 only; deeper entries go to LDS in code kept out of the common path
+__device__ __forceinline__ void path_put(PathRegs &pr, int d, int node, int act, double w1, int lane)
+{
+    const bool mine = lane == d;
+    pr.node = mine ? node : pr.node;
+    pr.act = mine ? act : pr.act;
+    pr.w_lo = mine ? __double2loint(w1) : pr.w_lo;
+    pr.w_hi = mine ? __double2hiint(w1) : pr.w_hi;
+}
+__device__ __forceinline__ void path_get(const PathRegs &pr, int d, int &node, int &act, double &w1)
+{
+    node = __builtin_amdgcn_readlane(pr.node, d);
+    act = __builtin_amdgcn_readlane(pr.act, d);
+    w1 = __hiloint2double(__builtin_amdgcn_readlane(pr.w_hi, d), __builtin_amdgcn_readlane(pr.w_lo, d));
+}
+
+// pops the top of the tree's free stack (caller has checked free_top > 0)
+__device__ __forceinline__ int pop_free(const AzParams &P, size_t tbase, int &free_top, int &batch, int &pos, int tid)
+{
+    if (pos == 64) { // refill: lane j takes the j-th entry below the top
+        const int lane = tid & 63;
+        const int idx = free_top - 1 - lane;
+        batch = idx >= 0 ? P.free_stack[tbase + idx] : -1;
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0), once per 64 expansions
+        pos = 0;
+    }
+    const int slot = __builtin_amdgcn_readlane(batch, pos);
+    pos++;
+    free_top--;
+    return slot;
+}
+
+// Diagnostic build (-DAZ_STAMPS): per-phase cycle sums of wavefront 0 of each
+// tree, written to P.stamps; never compiled into the shipped library.
+#ifdef AZ_STAMPS
+#define STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = __builtin_readcyclecounter();
+#define STAMP(i) do { unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_t; st_t = t_; } while (0)
+#define STAMP_FLUSH(tree) do { if (tid == 0 && P.stamps) for (int q = 0; q < 8; q++) P.stamps[(size_t)(tree) * 8 + q] = st_acc[q]; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i) do { } while (0)
+#define STAMP_FLUSH(tree) do { } while (0)
+#endif
+
 // ------------------------------------------------------------ fused simulate
 // Cmcts::simulate -> worker -> search (mcts/src/cmcts.cpp:83-282) for an
 // in-kernel evaluator: all n searches of one tree in one launch.  The root's
-// statistics stay in registers for the whole call (they are read by every
-// search) and are written back once at the end; deeper nodes stream from the
-// node pool.  Virtual loss (node.cpp:118) and its undo (node.cpp:80) are two
+// statistics stay in registers for the whole call (every search reads them)
+// and are written back once at the end; deeper nodes stream from the node
+// pool.  Virtual loss (node.cpp:118) and its undo (node.cpp:80) are two
 // separately rounded fp64 operations, kept as such: w1 = W - 1.0 at select,
 // W = w1 + (value + 1.0) at backup; only the final W is stored because no other
 // search of this tree can observe the intermediate.
-__global__ __launch_bounds__(64) void k_simulate_fused(AzParams P, AzFusedArgs A)
+template <int WPT>
+__global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFusedArgs A)
 {
+    constexpr int T = 64 * WPT;
+    static_assert(SP % T == 0, "group does not tile the padded action range");
+    constexpr int E = SP / T;
     const int tree = blockIdx.x;
-    const int lane = threadIdx.x;
-    AzTree *T = &P.trees[tree];
-    if (uni(T->active) == 0 || uni(T->err) != 0) return;
+    const int tid = threadIdx.x;
+    AzTree *Tr = &P.trees[tree];
+    if (uni(Tr->active) == 0 || uni(Tr->err) != 0) return;
 
-    __shared__ int s_node[PATH_CAP];
-    __shared__ int s_act[PATH_CAP];
-    __shared__ double s_w1[PATH_CAP];
+    // overflow of the register-resident path (depth > 64); every wavefront
+    // writes the same values
+    constexpr int PATH_SPILL = PATH_CAP > 64 ? PATH_CAP - 64 : 1;
+    __shared__ int s_node[PATH_SPILL];
+    __shared__ int s_act[PATH_SPILL];
+    __shared__ double s_w1[PATH_SPILL];
+    PathRegs path = {0, 0, 0, 0};
+    __shared__ Slot s_slots[2 * WPT];
+    int phase = 0;
 
     WState root_state;
-    load_state(P, tree, lane, root_state);
-    int root = uni(T->root);
-    int free_top = uni(T->free_top);
-    int n_order = uni(T->n_order);
+    load_state<E>(P, tree, tid, root_state);
+    int root = uni(Tr->root);
+    int free_top = uni(Tr->free_top);
+    int n_order = uni(Tr->n_order);
     int noise_row = 0;
     int err = 0;
     const size_t tbase = (size_t)tree * P.cap;
     unsigned long long n_sims = 0, n_exp = 0, n_term = 0, n_sel = 0;
 
-    NodeRegs R;
+    NodeRegs<E> R;
     int root_n = 0;
     if (root >= 0) {
-        load_node(P, tree, root, lane, R);
-        root_n = uni(P.node_n[tbase + root]);
+        load_node<E>(P, tree, root, tid, false, R); // a root is always materialised
+        root_n = uni(Tr->root_n);
     }
-    // next free slot is fetched one expansion ahead so its latency is hidden
-    // (kept in a vector register: the wait lands at its first use, not here)
-    int next_free = free_top > 0 ? P.free_stack[tbase + free_top - 1] : -1;
+    // The root registers must be complete BEFORE the search loop: otherwise the
+    // compiler guards their first use inside the loop with s_waitcnt vmcnt(0),
+    // which on every iteration also waits for the previous search's stores.
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+    // Free slots are popped from a 64-entry batch held in one vector register
+    // (lane j = j-th next pop), refilled every 64 expansions: a pop is a
+    // v_readlane, not a dependent memory load on the critical path.
+    int fs_batch = 0, fs_pos = 64;
+    STAMP_DECL
 
+    int worker_left = 0;
     for (int i = 0; i < A.n_total && err == 0; ++i) {
-        if (A.per_worker > 0 && i % A.per_worker == 0) noise_row = 0; // new worker, new generator (cmcts.cpp:132-133)
+        if (worker_left == 0) { // new worker, new generator (cmcts.cpp:132-133)
+            noise_row = 0;
+            worker_left = A.per_worker > 0 ? A.per_worker : A.n_total;
+        }
+        worker_left--;
         WState s = root_state;
 
         if (root < 0) {
             // first search on a fresh root only expands it (cmcts.cpp:190-243)
             if (free_top == 0) { err = AZ_ERR_POOL_FULL; break; }
             if (P.noise != nullptr && noise_row >= P.noise_rows) { err = AZ_ERR_NOISE_ROWS; break; }
-            const int slot = uni(next_free);
-            free_top--;
-            if (lane == 0) P.order[tbase + n_order] = slot;
+            const int slot = pop_free(P, tbase, free_top, fs_batch, fs_pos, tid);
+            if (tid == 0) { P.order[tbase + n_order] = slot; P.parent[tbase + slot] = -1; }
             n_order++;
-            next_free = free_top > 0 ? P.free_stack[tbase + free_top - 1] : -1;
-            float pr[EPL];
-            (void)evaluate(A, s, lane, pr);
-            mix_prior(P, pr, false, noise_row, lane, R.p);
+            float pr[E];
+            (void)evaluate<E>(A, s, tid, pr);
+            mix_prior<E>(P, pr, false, noise_row, tid, R.p);
             if (P.noise != nullptr) noise_row++;
+            st_f64<E>(rec_ptr(P, tree, slot) + OFF_P, tid, R.p);
 #pragma unroll
-            for (int k = 0; k < EPL; k++) { R.n[k] = 0; R.link[k] = 0; R.w[k] = 0.; }
+            for (int k = 0; k < E; k++) { R.n[k] = 0; R.link[k] = 0; R.w[k] = 0.; }
             root_n = 0;
             root = slot;
-            if (lane == 0) P.parent[tbase + slot] = -1;
             n_exp++; n_sims++;
+            __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): noise loads into the root registers are complete
             continue;
         }
 
         // level 0: the root, in registers
-        int wl, wk;
-        int a = select_action(R, root_n, s.occ, P.cpuct, lane, wl, wk);
-        if (a < 0) { err = AZ_ERR_NO_ACTION; break; }
+        STAMP(7);
+        Pick pk = select_pick<WPT, E>(R, root_n, s.occ, P.cpuct, tid, s_slots, phase, P.no_screen == 0);
+        STAMP(0);
+        if (pk.a < 0) { err = AZ_ERR_NO_ACTION; break; }
         n_sel++;
-        int my_link = 0;
+        const int root_a = pk.a;
 #pragma unroll
-        for (int k = 0; k < EPL; k++)
-            if (lane == wl && k == wk) {
+        for (int k = 0; k < E; k++)
+            if (tid == root_a / E && k == root_a % E) {
                 R.n[k] += 1;
                 R.w[k] -= 1.; // virtual loss (node.cpp:118)
-                my_link = R.link[k];
             }
         root_n += 1;
-        int link = lane_bcast_i32(my_link, wl);
-        const int root_l = wl, root_k = wk;
-        state_move(s, a, lane);
 
         int depth = 0;           // path entries below the root
         int parent_slot = root;  // node that will own the link to a new child
-        int parent_a = a;
+        int parent_a = pk.a;
         float value = 0.f;
         for (;;) {
+            // pk = the pick made at the node above; its move is not applied yet.
+            // The child's nodeN is the parent's visit count of the action minus
+            // the visit that created it.  Its record is requested BEFORE the
+            // move is applied so the rules code overlaps the memory latency.
+            const int cur = pk.link - 1;
+            const int nn = pk.n - 1;
+            const bool fresh = nn == 0;
+            NodeRegs<E> nd;
+            if (cur >= 0) load_node<E>(P, tree, cur, tid, fresh, nd);
+            state_move<E>(s, pk.a, tid);
+            STAMP(1);
             if (s.winner != -1.f) { // cmcts.cpp:253-267: no node for a finished game
                 value = (s.winner == 0.f || s.winner == 1.f) ? 1.f : 0.f;
                 n_term++;
                 break;
             }
-            if (link == 0) { // Node::next_node creates the child (node.cpp:126-134), the loop expands it
+            if (cur < 0) { // Node::next_node creates the child (node.cpp:126-134), the loop expands it
                 if (free_top == 0) { err = AZ_ERR_POOL_FULL; break; }
                 if (P.noise != nullptr && noise_row >= P.noise_rows) { err = AZ_ERR_NOISE_ROWS; break; }
-                const int slot = uni(next_free);
-                free_top--;
-                if (lane == 0) P.order[tbase + n_order] = slot;
+                const int slot = pop_free(P, tbase, free_top, fs_batch, fs_pos, tid);
+                if (tid == 0) { P.order[tbase + n_order] = slot; P.parent[tbase + slot] = parent_slot; }
                 n_order++;
-                next_free = free_top > 0 ? P.free_stack[tbase + free_top - 1] : -1;
-                float pr[EPL];
-                const float v = evaluate(A, s, lane, pr);
-                double pp[EPL];
-                mix_prior(P, pr, false, noise_row, lane, pp);
+                float pr[E];
+                const float v = evaluate<E>(A, s, tid, pr);
+                double pp[E];
+                mix_prior<E>(P, pr, false, noise_row, tid, pp);
                 if (P.noise != nullptr) noise_row++;
-                write_new_node(P, tree, slot, parent_slot, pp, lane);
-                if (depth == 0) {
+#ifndef AZ_EXP_NOBULK
+                st_f64<E>(rec_ptr(P, tree, slot) + OFF_P, tid, pp); // statistics stay implicit zeros
+#endif
+                if (tid == parent_a / E) {
+                    if (depth == 0) {
 #pragma unroll
-                    for (int k = 0; k < EPL; k++)
-                        if (lane == root_l && k == root_k) R.link[k] = slot + 1;
-                } else if (lane == 0) {
-                    reinterpret_cast<int *>(rec_ptr(P, tree, parent_slot) + OFF_LINK)[parent_a] = slot + 1;
+                        for (int k = 0; k < E; k++)
+                            if (k == parent_a % E) R.link[k] = slot + 1;
+                    } else {
+                        reinterpret_cast<int *>(rec_ptr(P, tree, parent_slot) + OFF_LINK)[parent_a] = slot + 1;
+                    }
                 }
                 value = -v; // cmcts.cpp:228
                 n_exp++;
+                STAMP(4);
                 break;
             }
-            const int cur = link - 1;
-            NodeRegs nd;
-            load_node(P, tree, cur, lane, nd);
-            const int nn = uni(P.node_n[tbase + cur]);
-            a = select_action(nd, nn, s.occ, P.cpuct, lane, wl, wk);
-            if (a < 0) { err = AZ_ERR_NO_ACTION; break; }
+#ifdef AZ_STAMPS
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            STAMP(2);
+#endif
+            pk = select_pick<WPT, E>(nd, nn, s.occ, P.cpuct, tid, s_slots, phase, P.no_screen == 0);
+            STAMP(3);
+            if (pk.a < 0) { err = AZ_ERR_NO_ACTION; break; }
             n_sel++;
-            int my_n = 0;
-            double my_w = 0.;
-            my_link = 0;
+            if (fresh) { // first select on this node: materialise its statistics
+                // (from registers of their own: reusing the load targets would
+                // make later loads wait for these stores to complete)
+                NodeRegs<E> z;
 #pragma unroll
-            for (int k = 0; k < EPL; k++)
-                if (k == wk) { my_n = nd.n[k]; my_w = nd.w[k]; my_link = nd.link[k]; }
-            if (lane == wl) reinterpret_cast<int *>(rec_ptr(P, tree, cur) + OFF_N)[a] = my_n + 1;
-            if (lane == 0) P.node_n[tbase + cur] = nn + 1;
-            const double w1 = lane_bcast_f64(my_w, wl) - 1.; // virtual loss
-            link = lane_bcast_i32(my_link, wl);
-            s_node[depth] = cur;
-            s_act[depth] = a;
-            s_w1[depth] = w1;
+                for (int k = 0; k < E; k++) {
+                    z.n[k] = (tid == pk.a / E && k == pk.a % E) ? 1 : 0;
+                    z.link[k] = 0;
+                    z.w[k] = 0.;
+                }
+#ifndef AZ_EXP_NOBULK
+                store_stats<E>(P, tree, cur, tid, z);
+#endif
+            } else if (tid == pk.a / E) {
+                reinterpret_cast<int *>(rec_ptr(P, tree, cur) + OFF_N)[pk.a] = pk.n + 1;
+            }
+            if (__builtin_expect(depth >= 64, 0)) {
+                s_node[depth - 64] = cur; s_act[depth - 64] = pk.a; s_w1[depth - 64] = pk.w - 1.;
+            } else {
+                path_put(path, depth, cur, pk.a, pk.w - 1. /* virtual loss */, tid & 63);
+            }
             depth++;
             parent_slot = cur;
-            parent_a = a;
-            state_move(s, a, lane);
+            parent_a = pk.a;
+            STAMP(5);
         }
         if (err != 0) break;
-        // backup (cmcts.cpp:271-279, node.cpp:75-83): deepest first, sign flips
-        for (int d = depth - 1; d >= 0; --d) {
-            if (lane == 0)
-                reinterpret_cast<double *>(rec_ptr(P, tree, s_node[d]) + OFF_W)[s_act[d]] =
-                    s_w1[d] + ((double)value + 1.);
+        // backup (cmcts.cpp:271-279, node.cpp:75-83): deepest first, sign flips;
+        // each W word is written by the thread that owns (and later re-reads) it
+        int d = depth - 1;
+        for (; __builtin_expect(d >= 64, 0); --d) { // entries spilled to LDS (rare)
+            const int act = s_act[d - 64];
+            if (tid == act / E)
+                reinterpret_cast<double *>(rec_ptr(P, tree, s_node[d - 64]) + OFF_W)[act] =
+                    s_w1[d - 64] + ((double)value + 1.);
+            value = -value;
+        }
+        for (; d >= 0; --d) {
+            int node, act;
+            double w1;
+            path_get(path, d, node, act, w1);
+            if (tid == act / E)
+                reinterpret_cast<double *>(rec_ptr(P, tree, node) + OFF_W)[act] = w1 + ((double)value + 1.);
             value = -value;
         }
 #pragma unroll
-        for (int k = 0; k < EPL; k++)
-            if (lane == root_l && k == root_k) R.w[k] += (double)value + 1.;
+        for (int k = 0; k < E; k++)
+            if (tid == root_a / E && k == root_a % E) R.w[k] += (double)value + 1.;
         n_sims++;
+        STAMP(6);
     }
+    STAMP_FLUSH(tree);
 
-    if (root >= 0) {
-        store_node(P, tree, root, lane, R);
-        if (lane == 0) P.node_n[tbase + root] = root_n;
-    }
-    if (lane == 0) {
-        T->root = root;
-        T->free_top = free_top;
-        T->n_order = n_order;
-        T->noise_row = noise_row;
-        if (err) T->err = err;
-        T->stats[0] += n_sims;
-        T->stats[1] += n_exp;
-        T->stats[2] += n_term;
-        T->stats[3] += n_sel;
+    if (root >= 0) store_stats<E>(P, tree, root, tid, R);
+    if (tid == 0) {
+        Tr->root = root;
+        Tr->root_n = root_n;
+        Tr->free_top = free_top;
+        Tr->n_order = n_order;
+        Tr->noise_row = noise_row;
+        if (err) Tr->err = err;
+        Tr->stats[0] += n_sims;
+        Tr->stats[1] += n_exp;
+        Tr->stats[2] += n_term;
+        Tr->stats[3] += n_sel;
     }
 }
 
 // --------------------------------------------------------------- step: select
 // Cmcts::search down to the leaf (mcts/src/cmcts.cpp:189-268) for an external
-// evaluator.  Virtual loss is stored (node.cpp:115-118) because the backup
-// runs in a later launch.
+// evaluator, one wavefront per tree.  Virtual loss is stored
+// (node.cpp:115-118) because the backup runs in a later launch.
 __global__ __launch_bounds__(64) void k_select(AzParams P, float *d_boards, int *d_leaf_kind)
 {
+    constexpr int E = EPL;
     const int tree = blockIdx.x;
     const int lane = threadIdx.x;
     AzTree *T = &P.trees[tree];
@@ -587,45 +864,46 @@ __global__ __launch_bounds__(64) void k_select(AzParams P, float *d_boards, int 
         return;
     }
     WState s;
-    load_state(P, tree, lane, s);
-    const size_t tbase = (size_t)tree * P.cap;
+    load_state<E>(P, tree, lane, s);
     int *pn = P.path_node + (size_t)tree * P.path_cap;
     int *pa = P.path_act + (size_t)tree * P.path_cap;
-    int cur = uni(T->root);
-    int depth = 0, kind = AZ_LEAF_EXPAND, err = 0;
+    const int root = uni(T->root);
+    int cur = root;
+    int nn = root >= 0 ? uni(T->root_n) : 0;
+    int depth = 0, kind = AZ_LEAF_EXPAND, err = 0, phase = 0;
     float leaf_value = 0.f;
     unsigned long long n_sel = 0;
     while (cur >= 0) {
-        NodeRegs nd;
-        load_node(P, tree, cur, lane, nd);
-        const int nn = uni(P.node_n[tbase + cur]);
-        int wl, wk;
-        const int a = select_action(nd, nn, s.occ, P.cpuct, lane, wl, wk);
-        if (a < 0) { err = AZ_ERR_NO_ACTION; break; }
+        const bool fresh = nn == 0 && cur != root; // a root is always materialised
+        NodeRegs<E> nd;
+        load_node<E>(P, tree, cur, lane, fresh, nd);
+        const Pick pk = select_pick<1, E>(nd, nn, s.occ, P.cpuct, lane, nullptr, phase, P.no_screen == 0);
+        if (pk.a < 0) { err = AZ_ERR_NO_ACTION; break; }
         n_sel++;
-        int my_link = 0;
+        char *rec = rec_ptr(P, tree, cur);
+        if (fresh) {
 #pragma unroll
-        for (int k = 0; k < EPL; k++)
-            if (lane == wl && k == wk) {
-                char *rec = rec_ptr(P, tree, cur);
-                reinterpret_cast<int *>(rec + OFF_N)[a] = nd.n[k] + 1;
-                reinterpret_cast<double *>(rec + OFF_W)[a] = nd.w[k] - 1.;
-                my_link = nd.link[k];
-            }
+            for (int k = 0; k < E; k++)
+                if (lane == pk.a / E && k == pk.a % E) { nd.n[k] = 1; nd.w[k] = -1.; }
+            store_stats<E>(P, tree, cur, lane, nd);
+        } else if (lane == pk.a / E) {
+            reinterpret_cast<int *>(rec + OFF_N)[pk.a] = pk.n + 1;
+            reinterpret_cast<double *>(rec + OFF_W)[pk.a] = pk.w - 1.;
+        }
         if (lane == 0) {
-            P.node_n[tbase + cur] = nn + 1;
+            if (cur == root) T->root_n = nn + 1;
             pn[depth] = cur;
-            pa[depth] = a;
+            pa[depth] = pk.a;
         }
         depth++;
-        const int link = lane_bcast_i32(my_link, wl);
-        state_move(s, a, lane);
+        state_move<E>(s, pk.a, lane);
         if (s.winner != -1.f) {
             kind = AZ_LEAF_TERMINAL;
             leaf_value = (s.winner == 0.f || s.winner == 1.f) ? 1.f : 0.f;
             break;
         }
-        cur = link - 1; // -1 ends the walk: the child does not exist yet
+        cur = pk.link - 1; // -1 ends the walk: the child does not exist yet
+        nn = pk.n - 1;
     }
     if (err) kind = AZ_LEAF_NONE;
     if (kind == AZ_LEAF_EXPAND) write_board(s, d_boards + (size_t)tree * 2 * SIZE, lane);
@@ -645,6 +923,7 @@ __global__ __launch_bounds__(64) void k_select(AzParams P, float *d_boards, int 
 __global__ __launch_bounds__(64) void k_expand_backup(AzParams P, const float *d_value, const float *d_prior,
                                                        int prior_is_log)
 {
+    constexpr int E = EPL;
     const int tree = blockIdx.x;
     const int lane = threadIdx.x;
     AzTree *T = &P.trees[tree];
@@ -657,9 +936,9 @@ __global__ __launch_bounds__(64) void k_expand_backup(AzParams P, const float *d
     int err = 0;
     float value;
     if (kind == AZ_LEAF_EXPAND) {
-        int free_top = uni(T->free_top);
-        int n_order = uni(T->n_order);
-        int noise_row = uni(T->noise_row);
+        const int free_top = uni(T->free_top);
+        const int n_order = uni(T->n_order);
+        const int noise_row = uni(T->noise_row);
         if (free_top == 0) err = AZ_ERR_POOL_FULL;
         else if (P.noise != nullptr && noise_row >= P.noise_rows) err = AZ_ERR_NOISE_ROWS;
         if (err) {
@@ -667,21 +946,29 @@ __global__ __launch_bounds__(64) void k_expand_backup(AzParams P, const float *d
             return;
         }
         const int slot = uni(P.free_stack[tbase + free_top - 1]);
-        float pr[EPL];
+        float pr[E];
 #pragma unroll
-        for (int k = 0; k < EPL; k++) {
-            const int a = lane * EPL + k;
+        for (int k = 0; k < E; k++) {
+            const int a = lane * E + k;
             pr[k] = a < SIZE ? d_prior[(size_t)tree * SIZE + a] : 0.f;
         }
-        double pp[EPL];
-        mix_prior(P, pr, prior_is_log != 0, noise_row, lane, pp);
+        NodeRegs<E> nd;
+        mix_prior<E>(P, pr, prior_is_log != 0, noise_row, lane, nd.p);
+        st_f64<E>(rec_ptr(P, tree, slot) + OFF_P, lane, nd.p);
         const int parent_slot = depth > 0 ? uni(pn[depth - 1]) : -1;
-        write_new_node(P, tree, slot, parent_slot, pp, lane);
+        if (depth == 0) { // the new node is the root: materialise it
+#pragma unroll
+            for (int k = 0; k < E; k++) { nd.n[k] = 0; nd.link[k] = 0; nd.w[k] = 0.; }
+            store_stats<E>(P, tree, slot, lane, nd);
+        }
         if (lane == 0) {
-            if (depth > 0)
+            if (depth > 0) {
                 reinterpret_cast<int *>(rec_ptr(P, tree, parent_slot) + OFF_LINK)[pa[depth - 1]] = slot + 1;
-            else
+            } else {
                 T->root = slot;
+                T->root_n = 0;
+            }
+            P.parent[tbase + slot] = parent_slot;
             P.order[tbase + n_order] = slot;
             T->free_top = free_top - 1;
             T->n_order = n_order + 1;
@@ -720,6 +1007,7 @@ __global__ __launch_bounds__(64) void k_expand_backup(AzParams P, const float *d
 // back on the free stack.
 __global__ __launch_bounds__(64) void k_make_move(AzParams P, const int *d_actions)
 {
+    constexpr int E = EPL;
     extern __shared__ unsigned s_marks[];
     const int tree = blockIdx.x;
     const int lane = threadIdx.x;
@@ -727,25 +1015,34 @@ __global__ __launch_bounds__(64) void k_make_move(AzParams P, const int *d_actio
     const int a = uni(d_actions[tree]);
     if (a < 0) return;
     WState s;
-    load_state(P, tree, lane, s);
+    load_state<E>(P, tree, lane, s);
     // State::is_valid (state.cpp:29-37)
     bool ok = a < SIZE;
     if (ok) {
-        const unsigned long long occupied = __ballot(lane == a / EPL && ((s.occ >> (a % EPL)) & 1u));
+        const unsigned long long occupied = __ballot(lane == a / E && ((s.occ >> (a % E)) & 1u));
         ok = occupied == 0ull;
     }
     if (!ok) {
         if (lane == 0 && T->err == 0) T->err = AZ_ERR_INVALID_MOVE;
         return;
     }
-    state_move(s, a, lane);
+    state_move<E>(s, a, lane);
     P.rows[tree * 64 + lane] = s.rb;
-    P.occ[tree * 64 + lane] = s.occ;
 
     const size_t tbase = (size_t)tree * P.cap;
     const int root = uni(T->root);
-    int new_root = -1;
-    if (root >= 0) new_root = uni(reinterpret_cast<const int *>(rec_ptr(P, tree, root) + OFF_LINK)[a]) - 1;
+    int new_root = -1, new_root_n = -1;
+    if (root >= 0) {
+        const char *rec = rec_ptr(P, tree, root);
+        new_root = uni(reinterpret_cast<const int *>(rec + OFF_LINK)[a]) - 1;
+        new_root_n = uni(reinterpret_cast<const int *>(rec + OFF_N)[a]) - 1;
+    }
+    if (new_root >= 0 && new_root_n == 0) { // a never-selected node becomes the root: materialise it
+        NodeRegs<E> z;
+#pragma unroll
+        for (int k = 0; k < E; k++) { z.n[k] = 0; z.link[k] = 0; z.w[k] = 0.; }
+        store_stats<E>(P, tree, new_root, lane, z);
+    }
     const int n = uni(T->n_order);
     int free_top = uni(T->free_top);
     int kept = 0;
@@ -782,6 +1079,7 @@ __global__ __launch_bounds__(64) void k_make_move(AzParams P, const int *d_actio
     if (lane == 0) {
         if (new_root >= 0) P.parent[tbase + new_root] = -1;
         T->root = new_root;
+        T->root_n = new_root >= 0 ? new_root_n : -1;
         T->n_order = kept;
         T->free_top = free_top;
         T->player = s.player;
@@ -806,9 +1104,9 @@ __global__ __launch_bounds__(64) void k_clear(AzParams P, const unsigned char *d
         P.parent[tbase + idx] = -2;
     }
     P.rows[tree * 64 + lane] = 0u;
-    P.occ[tree * 64 + lane] = 0u;
     if (lane == 0) {
         T->root = -1;
+        T->root_n = -1;
         T->n_order = 0;
         T->free_top = free_top + n;
         T->player = 0;
@@ -824,6 +1122,7 @@ __global__ __launch_bounds__(64) void k_clear(AzParams P, const unsigned char *d
 // first-maximum arg-max of the root visit counts (pi.argmax(), src/eval.py:192)
 __global__ __launch_bounds__(64) void k_select_greedy(AzParams P, int *d_actions)
 {
+    constexpr int E = EPL;
     const int tree = blockIdx.x;
     const int lane = threadIdx.x;
     const AzTree *T = &P.trees[tree];
@@ -832,39 +1131,39 @@ __global__ __launch_bounds__(64) void k_select_greedy(AzParams P, int *d_actions
         if (lane == 0) d_actions[tree] = -1;
         return;
     }
-    int n[EPL];
-    ld_i32(rec_ptr(P, tree, root) + OFF_N, lane, n);
+    int n[E];
+    ld_i32<E>(rec_ptr(P, tree, root) + OFF_N, lane, n);
     int best = -1, bk = 0;
 #pragma unroll
-    for (int k = 0; k < EPL; k++)
-        if (lane * EPL + k < SIZE && n[k] > best) { best = n[k]; bk = k; }
+    for (int k = 0; k < E; k++)
+        if (lane * E + k < SIZE && n[k] > best) { best = n[k]; bk = k; }
     const int m = wave_max_i32(best);
     const unsigned long long mask = __ballot(best == m);
     const int wl = __ffsll((long long)mask) - 1;
     const int wk = lane_bcast_i32(bk, wl);
-    if (lane == 0) d_actions[tree] = wl * EPL + wk;
+    if (lane == 0) d_actions[tree] = wl * E + wk;
 }
 
 // Node::counts / nodeN of every root (node.cpp:160-164) into dense arrays
 __global__ __launch_bounds__(64) void k_get_counts(AzParams P, int *d_counts, int *d_root_n)
 {
+    constexpr int E = EPL;
     const int tree = blockIdx.x;
     const int lane = threadIdx.x;
     const AzTree *T = &P.trees[tree];
     const int root = uni(T->root);
-    int n[EPL];
+    int n[E];
 #pragma unroll
-    for (int k = 0; k < EPL; k++) n[k] = 0;
-    if (root >= 0) ld_i32(rec_ptr(P, tree, root) + OFF_N, lane, n);
+    for (int k = 0; k < E; k++) n[k] = 0;
+    if (root >= 0) ld_i32<E>(rec_ptr(P, tree, root) + OFF_N, lane, n);
     if (d_counts != nullptr) {
 #pragma unroll
-        for (int k = 0; k < EPL; k++) {
-            const int a = lane * EPL + k;
+        for (int k = 0; k < E; k++) {
+            const int a = lane * E + k;
             if (a < SIZE) d_counts[(size_t)tree * SIZE + a] = n[k];
         }
     }
-    if (d_root_n != nullptr && lane == 0)
-        d_root_n[tree] = root >= 0 ? P.node_n[(size_t)tree * P.cap + root] : -1;
+    if (d_root_n != nullptr && lane == 0) d_root_n[tree] = root >= 0 ? T->root_n : -1;
 }
 
 int launch_status()
@@ -872,9 +1171,26 @@ int launch_status()
     return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
 }
 
+// Wavefronts per tree for the fused kernel.  One wavefront per tree is the
+// default: the search is bound by the instruction stream of a single
+// wavefront, and splitting a tree over WPT_MAX wavefronts replicates the
+// scalar part of that stream in each of them (measured slower on MI355X at
+// 1024 trees).  The wide variant stays selectable (AzFusedArgs::waves_per_tree).
+int pick_wpt(const AzParams &P, const AzFusedArgs &A)
+{
+    int wpt = A.waves_per_tree;
+    if (wpt <= 0) wpt = 1;
+    if (wpt != 1 && wpt != WPT_MAX) wpt = wpt > 1 ? WPT_MAX : 1;
+    return wpt;
+}
+
 int l_simulate_fused(const AzParams &P, const AzFusedArgs &A, void *stream)
 {
-    hipLaunchKernelGGL(k_simulate_fused, dim3(P.n_trees), dim3(64), 0, (hipStream_t)stream, P, A);
+    const int wpt = pick_wpt(P, A);
+    const dim3 grid(P.n_trees);
+    hipStream_t st = (hipStream_t)stream;
+    if (wpt == 1) hipLaunchKernelGGL(k_simulate_fused<1>, grid, dim3(64), 0, st, P, A);
+    else hipLaunchKernelGGL(k_simulate_fused<WPT_MAX>, grid, dim3(64 * WPT_MAX), 0, st, P, A);
     return launch_status();
 }
 int l_select(const AzParams &P, float *d_boards, int *d_leaf_kind, void *stream)
@@ -920,7 +1236,7 @@ int l_get_counts(const AzParams &P, int *d_counts, int *d_root_n, void *stream)
 extern "C" const AzShapeOps *AZ_CAT(az_shape_ops_, AZ_S)(void)
 {
     static const AzShapeOps ops = {
-        AZ_S, l_simulate_fused, l_select, l_expand_backup, l_make_move, l_clear, l_select_greedy, l_get_counts,
+        AZ_S, SP, l_simulate_fused, l_select, l_expand_backup, l_make_move, l_clear, l_select_greedy, l_get_counts,
     };
     return &ops;
 }

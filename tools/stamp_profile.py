@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Phase breakdown of the fused search kernel from in-kernel cycle stamps.
+
+Needs the diagnostic library: `make -C alphazero_amd/csrc stamps`
+(libazmcts_stamps.so, 15x15 only).  Never used for throughput numbers: the
+stamps serialise the instruction stream.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from alphazero_amd import engine as E  # noqa: E402
+
+E.LIB_PATH = os.path.join(ROOT, "alphazero_amd", os.environ.get("AZ_STAMP_LIB", "libazmcts_stamps.so"))
+NAMES = ["root_select", "root_move", "node_load_wait", "node_select", "expand", "node_move", "backup", "loop_top"]
+
+
+def main():
+    trees = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    eng = E.Engine(trees, 15, nodes_per_tree=4096, cpuct=4.0)
+    eng.L.az_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
+    eng.set_eps(0.0)
+    size = 225
+    for ply in range(2):
+        act = np.array([(g % size, (g % size + 1 + (g // size) % (size - 1)) % size)[ply] for g in range(trees)], np.int32)
+        eng.make_move(act)
+    p = float(np.float32(1 / 225))
+    for it in range(3):
+        eng.timing_begin()
+        eng.simulate_fused(800, E.EVAL_UNIFORM, p, 0.0, 0, None, sync=False)
+        ms = eng.timing_end()
+        out = np.zeros((trees, 8), np.uint64)
+        eng._check(eng.L.az_debug_stamps(eng.h, out.ctypes.data))
+        tot = out.sum(axis=1).mean()
+        print(f"launch {it}: {ms:.3f} ms, mean cycles/tree {tot:.0f} ({tot / 800:.0f} per search)")
+        for n, v in zip(NAMES, out.mean(axis=0)):
+            print(f"   {n:16s} {v / 800:8.0f} cycles/search  {100 * v / tot:5.1f} %")
+        d = np.zeros(trees, np.int32)
+        import torch
+        da = torch.zeros(trees, dtype=torch.int32, device="cuda")
+        eng.select_greedy(da.data_ptr())
+        eng.make_move_device(da.data_ptr())
+        eng.sync_check()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -568,6 +568,25 @@ int az_get_raw_board(az_engine *e, int tree, signed char *board)
     return AZ_OK;
 }
 
+int az_get_raw_boards(az_engine *e, signed char *boards)
+{
+    if (!e || !boards) return fail(AZ_ERR_ARG, "null argument");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<unsigned> rows((size_t)e->n_trees * 64);
+    HIP_TRY(hipMemcpy(rows.data(), e->P.rows, rows.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+    const int S = e->shape;
+    for (int t = 0; t < e->n_trees; t++) {
+        signed char *b = boards + (size_t)t * 2 * e->size;
+        for (int pl = 0; pl < 2; pl++)
+            for (int r = 0; r < S; r++) {
+                const unsigned bits = rows[(size_t)t * 64 + pl * 32 + r];
+                for (int c = 0; c < S; c++) b[pl * e->size + r * S + c] = (signed char)((bits >> c) & 1u);
+            }
+    }
+    return AZ_OK;
+}
+
 int az_get_board(az_engine *e, int tree, float *board)
 {
     if (int rc = check_tree(e, tree)) return rc;

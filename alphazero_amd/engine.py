@@ -60,6 +60,7 @@ SYMBOLS = [
     ("az_get_prob", _i, [_vp, _i, _vp]),
     ("az_get_board", _i, [_vp, _i, _vp]),
     ("az_get_raw_board", _i, [_vp, _i, _vp]),
+    ("az_get_raw_boards", _i, [_vp, _vp]),
     ("az_get_node", _i, [_vp, _i, _vp, _i, C.POINTER(_i), C.POINTER(_i), _vp, _vp, _vp]),
     ("az_get_stats", _i, [_vp] + [C.POINTER(_ull)] * 4),
     ("az_reset_stats", _i, [_vp]),
@@ -255,6 +256,11 @@ class Engine:
     def get_raw_board(self, tree):
         out = np.empty((2, self.shape, self.shape), np.int8)
         self._check(self.L.az_get_raw_board(self.h, tree, _ptr(out)))
+        return out
+
+    def get_raw_boards(self):
+        out = np.empty((self.n_trees, 2, self.shape, self.shape), np.int8)
+        self._check(self.L.az_get_raw_boards(self.h, _ptr(out)))
         return out
 
     def get_node(self, tree, path):

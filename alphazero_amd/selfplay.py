@@ -1,0 +1,288 @@
+"""Batched self-play and arena drivers.
+
+The reference plays ONE game at a time with two `cmcts.mcts` objects
+(`self_play_game`, src/self_play.py:134-202; `eval_game`, src/eval.py:187-209).
+Here the same per-move protocol runs for thousands of games in lock step: each
+side owns one engine with one tree per game, a search step evaluates every
+tree's leaf in a single batched network call, and games are independent, so
+they shard over GPUs with no collective inside the search (gather_samples /
+reduce_counters are the only exchanges, over RCCL when launched with one
+process per GPU).
+"""
+import numpy as np
+
+from . import engine as _E
+
+
+def sample_dtype(shape):
+    """Record layout of the reference's training samples (src/self_play.py:153)."""
+    return np.dtype([("board", "f4", (2, shape, shape)), ("pi", "f4", (shape * shape,)), ("r", "f4")])
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous block of game indices owned by `rank` (independent games shard naturally)."""
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+class TreeBatch:
+    """`n_trees` reference `cmcts.mcts` objects driven together by one evaluator."""
+
+    def __init__(self, n_trees, shape, evaluator, cpuct=1.0, eps=0.25, alpha=None, threads=0,
+                 nodes_per_tree=4096, device=0, noise_seed=0):
+        import torch
+
+        self.torch = torch
+        self.eng = _E.Engine(n_trees, shape, nodes_per_tree, 1.0 if alpha is None else alpha, cpuct, device)
+        if alpha is None:
+            self.eng.set_alpha_default()  # what the callers do (src/self_play.py:70, src/eval.py:83)
+        self.eng.set_eps(eps)
+        self.eng.set_threads(threads)
+        self.n_trees, self.shape, self.size = n_trees, shape, shape * shape
+        self.evaluator = evaluator
+        self.noise_seed = noise_seed
+        self._noise_rows = 0
+        self.dev = torch.device("cuda", device)
+        self.boards = torch.zeros((n_trees, 2, shape, shape), dtype=torch.float32, device=self.dev)
+        self.kinds = torch.zeros(n_trees, dtype=torch.int32, device=self.dev)
+
+    def close(self):
+        self.eng.close()
+
+    def _ensure_noise(self, rows):
+        if self.eng.get_eps() == 0.0 or rows <= self._noise_rows:
+            return
+        rows = max(rows, 1024)
+        rng = np.random.default_rng(self.noise_seed)
+        self.eng.set_noise_table(rng.dirichlet(np.full(self.size, self.eng.get_alpha()), size=rows))
+        self._noise_rows = rows
+
+    def set_noise_table(self, table):
+        self.eng.set_noise_table(table)
+        self._noise_rows = 1 << 30 if table is not None else 0
+
+    def simulate(self, n, active=None):
+        """Cmcts::simulate(n) (cmcts.cpp:83-125) on the active trees; one batched
+        evaluator call per search step."""
+        if n < 1:
+            raise RuntimeError(f"Invalid input {n} must be at least 1!")
+        eng, torch = self.eng, self.torch
+        eng.set_active(None if active is None else np.asarray(active, np.uint8))
+        th_num, per = 1, n
+        threads = eng.get_threads()
+        if threads > 1:  # cmcts.cpp:98-107
+            th_num = threads
+            if n < th_num:
+                th_num, per = n, 1
+            elif n % th_num == 0:
+                per = n // th_num
+            else:
+                per = n // th_num + 1
+        self._ensure_noise(per)
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        with torch.no_grad():
+            for _ in range(th_num):
+                eng.begin_simulate(stream)
+                for _ in range(per):
+                    eng.select(self.boards.data_ptr(), self.kinds.data_ptr(), stream)
+                    value, prior = self.evaluator(self.boards)
+                    eng.expand_backup(value.data_ptr(), prior.data_ptr(), self.evaluator.log_priors, stream)
+        try:
+            eng.sync_check(stream)
+        except _E.EngineError as e:
+            raise RuntimeError(str(e)) from None
+
+    def probs(self, trees=None):
+        """Cmcts::get_prob (cmcts.cpp:317-341) for many trees: float32 [n, SIZE];
+        raises "Not a distribution" like the reference."""
+        counts, root_n = self.eng.get_counts()
+        if trees is not None:
+            counts, root_n = counts[trees], root_n[trees]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            pi = (counts.astype(np.float64) / root_n.astype(np.float64)[:, None]).astype(np.float32)
+        bad = np.round(pi.astype(np.float64).sum(axis=1) * 1000.0) != 1000
+        if bad.any():
+            raise RuntimeError("Not a distribution")
+        return pi
+
+    def boards_to_move(self, trees=None):
+        """State::get_board (state.cpp:39-48) for many trees: plane 0 = side to move."""
+        raw = self.eng.get_raw_boards().astype(np.float32)
+        player, _, _ = self.eng.get_states()
+        swap = player == 1
+        raw[swap] = raw[swap][:, ::-1]
+        return raw if trees is None else raw[trees]
+
+    def make_move(self, actions):
+        try:
+            self.eng.make_move(np.asarray(actions, np.int32))
+        except _E.EngineError as e:
+            raise RuntimeError(str(e)) from None
+
+    def winners(self):
+        return self.eng.get_states()[2]
+
+
+def _choose_moves(pi, greedy, rng):
+    """src/self_play.py:159-164: argmax + one-hot pi when greedy, else sample from pi."""
+    moves = np.empty(pi.shape[0], np.int64)
+    for j in range(pi.shape[0]):
+        if greedy:
+            m = int(pi[j].argmax())
+            pi[j, :] = 0
+            pi[j, m] = 1
+        else:
+            p = pi[j].astype(np.float64)
+            m = int(rng.choice(pi.shape[1], p=p / p.sum()))
+        moves[j] = m
+    return moves
+
+
+def self_play_games(batch0, batch1, sims, tau, init_moves=(), rng=None):
+    """`self_play_game` (src/self_play.py:134-202) for every game of the two batches.
+
+    batch0 / batch1: TreeBatch of equal size, tree g of each = mcts0 / mcts1 of game g.
+    Returns a list with one structured array per game (dtype sample_dtype), first
+    player's records first, labelled r = 1 / -1, or 1e-3 everywhere for a draw.
+    """
+    rng = np.random.default_rng() if rng is None else rng
+    G, S, size = batch0.n_trees, batch0.shape, batch0.size
+    assert batch1.n_trees == G and batch1.shape == S
+    dt = sample_dtype(S)
+    for m in init_moves:  # tools.make_init_moves (src/tools.py:41-44)
+        batch0.make_move(np.full(G, m, np.int32))
+        batch1.make_move(np.full(G, m, np.int32))
+    data = [([], []) for _ in range(G)]
+    alive = np.ones(G, bool)
+    for i in range(size):
+        for side, searcher in ((0, batch0), (1, batch1)):
+            if not alive.any():
+                break
+            idx = np.flatnonzero(alive)
+            searcher.simulate(sims, alive)
+            pi = searcher.probs(idx)
+            boards = searcher.boards_to_move(idx)
+            moves = _choose_moves(pi, i > tau, rng)
+            for j, g in enumerate(idx):
+                data[g][side].append((boards[j], pi[j].copy(), -1.0))
+            act = np.full(G, -1, np.int32)
+            act[idx] = moves
+            batch0.make_move(act)
+            batch1.make_move(act)
+            alive &= batch0.winners() == -1.0  # src/self_play.py:169,185
+        if not alive.any():
+            break
+    winner = batch0.winners()
+    out = []
+    for g in range(G):
+        rec = np.array([(b, p, r) for b, p, r in data[g][0] + data[g][1]], dtype=dt)
+        n0 = len(data[g][0])
+        if winner[g] == 0.0:
+            rec["r"][:n0] = 1.0
+        elif winner[g] == 1.0:
+            rec["r"][n0:] = 1.0
+        else:
+            rec["r"] = 1e-3  # draw (or the move limit was reached)
+        out.append(rec)
+    return out
+
+
+def eval_games(best, latest, sims_best, sims_latest, init_moves=()):
+    """`eval_models`' game loop (src/eval.py:111-149,187-209) for every game at once.
+
+    best / latest: TreeBatch of equal size holding the two networks' trees.  Game g
+    is opened by `best` when g is even, by `latest` when odd (src/eval.py:117,134).
+    Returns (wins_best, wins_latest, draws).
+    """
+    G, size = best.n_trees, best.size
+    assert latest.n_trees == G
+    for m in init_moves:
+        best.make_move(np.full(G, m, np.int32))
+        latest.make_move(np.full(G, m, np.int32))
+    first_player = int(best.eng.get_state(0)[0]) if G else 0  # src/eval.py:105
+    second_player = 1 - first_player
+    best_opens = (np.arange(G) % 2) == 0
+    alive = np.ones(G, bool)
+    for _ in range(size):
+        for half in (0, 1):
+            if not alive.any():
+                break
+            best_to_move = best_opens if half == 0 else ~best_opens
+            act = np.full(G, -1, np.int32)
+            for batch, mine, sims in ((best, best_to_move, sims_best), (latest, ~best_to_move, sims_latest)):
+                mask = alive & mine
+                if not mask.any():
+                    continue
+                batch.simulate(sims, mask)
+                idx = np.flatnonzero(mask)
+                act[idx] = batch.probs(idx).argmax(axis=1)  # always greedy (src/eval.py:192,202)
+            best.make_move(act)
+            latest.make_move(act)
+            alive &= best.winners() == -1.0
+        if not alive.any():
+            break
+    winner = best.winners()
+    wins_best = wins_latest = draws = 0
+    for g in range(G):
+        opener_won = winner[g] == first_player
+        other_won = winner[g] == second_player
+        if not (opener_won or other_won):
+            draws += 1
+        elif opener_won == bool(best_opens[g]):
+            wins_best += 1
+        else:
+            wins_latest += 1
+    return wins_best, wins_latest, draws
+
+
+def promote(wins_best, wins_latest, threshold=0.6):
+    """src/eval.py:176-180 with EVAL_TRESHOLD (general_config.py:24)."""
+    return wins_latest / (wins_latest + wins_best) >= threshold
+
+
+# ---------------------------------------------------------------- multi-GPU
+def gather_samples(samples, group=None):
+    """All ranks' sample arrays on every rank (one all_gather; RCCL over xGMI with
+    the nccl backend, gloo on CPU).  `samples`: structured array of this rank."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return samples
+    world = dist.get_world_size(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    raw = np.frombuffer(samples.tobytes(), np.uint8)
+    n = torch.tensor([raw.size], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(sizes) if sizes else 0
+    buf = torch.zeros(max(cap, 1), dtype=torch.uint8, device=dev)
+    buf[: raw.size] = torch.from_numpy(raw.copy()).to(dev)
+    parts = [torch.zeros(max(cap, 1), dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(parts, buf, group=group)
+    chunks = [np.frombuffer(p[:s].cpu().numpy().tobytes(), dtype=samples.dtype) for p, s in zip(parts, sizes)]
+    return np.concatenate(chunks) if chunks else samples
+
+
+def reduce_counters(values, group=None):
+    """Sum of per-rank counters (sims, expansions, wins ...) over all ranks."""
+    import torch
+    import torch.distributed as dist
+
+    arr = np.asarray(values, np.float64)
+    if not (dist.is_available() and dist.is_initialized()):
+        return arr
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.from_numpy(arr.copy()).to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().numpy()
+
+
+def save_samples(path, games):
+    """One `.npy` structured array, the file format src/train.py loads
+    (np.save at src/self_play.py:111,128)."""
+    data = np.concatenate(games) if isinstance(games, (list, tuple)) else games
+    np.save(path, data)
+    return data

@@ -161,6 +161,9 @@ int az_get_board(az_engine *e, int tree, float *board);
 /* raw planes as the evaluator sees them (cmcts.cpp:206-210): int8 [2][S][S] */
 int az_get_raw_board(az_engine *e, int tree, signed char *board);
 
+/* the same for every tree at once: int8 [n_trees][2][S][S] (host) */
+int az_get_raw_boards(az_engine *e, signed char *boards);
+
 /* introspection for parity tests and print_node (cmcts.cpp:404-417): walks from
  * the root of `tree` along path[0..len).  Returns AZ_OK and fills node_n,
  * counts[SIZE], w[SIZE], p[SIZE] (any may be NULL), or sets *found = 0 when a

@@ -1,0 +1,184 @@
+"""GPU parity of the batched self-play and arena drivers against the
+reference-shaped game loops run on the CPU oracle (same evaluator, same noise,
+same move rule): identical training records, outcomes and tallies."""
+import numpy as np
+import pytest
+
+import az_oracle_py as O
+from helpers import (ExactTorchEvaluator, exact_eval_numpy, oracle_eval_game, oracle_exact_evaluator,
+                     oracle_self_play_game)
+
+pytestmark = pytest.mark.gpu
+
+
+def _noise(rows, size, alpha, seed):
+    return np.random.default_rng(seed).dirichlet(np.full(size, alpha), size=rows)
+
+
+@pytest.mark.parametrize("S,sims,tau,eps", [(9, 40, -1, 0.25), (7, 30, -1, 0.0), (15, 25, -1, 0.25)])
+def test_self_play_games_match_reference_loop(S, sims, tau, eps):
+    from alphazero_amd import selfplay as sp
+
+    G, size = 4, S * S
+    ev = ExactTorchEvaluator()
+    b0 = sp.TreeBatch(G, S, ev, cpuct=4.0, eps=eps, nodes_per_tree=sims * 6)
+    b1 = sp.TreeBatch(G, S, ev, cpuct=4.0, eps=eps, nodes_per_tree=sims * 6)
+    noise = None
+    if eps > 0:
+        noise = _noise(sims + 2, size, b0.eng.get_alpha(), 3)
+        b0.set_noise_table(noise)
+        b1.set_noise_table(noise)
+    # give every game its own opening so the four games differ
+    for ply in range(2):
+        act = np.array([O.opening(size, g * 5 + 1)[ply] for g in range(G)], np.int32)
+        b0.make_move(act)
+        b1.make_move(act)
+    games = sp.self_play_games(b0, b1, sims, tau, rng=np.random.default_rng(0))
+    oev = oracle_exact_evaluator(S)
+    for g in range(G):
+        t0, t1 = O.OracleTree(S, cpuct=4.0), O.OracleTree(S, cpuct=4.0)
+        for t in (t0, t1):
+            t.set_alpha_default()
+            t.set_eps(eps)
+            for ply in range(2):
+                t.make_move(O.opening(size, g * 5 + 1)[ply])
+        recs, n0 = oracle_self_play_game(t0, t1, sims, tau, oev, np.random.default_rng(0), noise)
+        got = games[g]
+        assert got.dtype == sp.sample_dtype(S)
+        assert len(got) == len(recs), (g, len(got), len(recs))
+        for k, (board, pi, r) in enumerate(recs):
+            assert np.array_equal(got["board"][k], board), (g, k)
+            assert np.array_equal(got["pi"][k], pi), (g, k)
+            assert got["r"][k] == np.float32(r), (g, k)
+        assert float(b0.winners()[g]) == t0.winner
+    b0.close()
+    b1.close()
+
+
+def test_self_play_sampled_moves_single_game():
+    # temperature phase: moves drawn from pi with the caller's generator
+    from alphazero_amd import selfplay as sp
+
+    S, sims, tau = 7, 30, 3
+    ev = ExactTorchEvaluator()
+    b0 = sp.TreeBatch(1, S, ev, cpuct=4.0, eps=0.0, nodes_per_tree=400)
+    b1 = sp.TreeBatch(1, S, ev, cpuct=4.0, eps=0.0, nodes_per_tree=400)
+    games = sp.self_play_games(b0, b1, sims, tau, rng=np.random.default_rng(42))
+    t0, t1 = O.OracleTree(S, cpuct=4.0), O.OracleTree(S, cpuct=4.0)
+    for t in (t0, t1):
+        t.set_eps(0.0)
+    recs, n0 = oracle_self_play_game(t0, t1, sims, tau, oracle_exact_evaluator(S), np.random.default_rng(42))
+    assert len(games[0]) == len(recs)
+    for k, (board, pi, r) in enumerate(recs):
+        assert np.array_equal(games[0]["pi"][k], pi) and np.array_equal(games[0]["board"][k], board)
+        assert games[0]["r"][k] == np.float32(r)
+    # sampled plies keep the full distribution, greedy plies are one-hot (src/self_play.py:159-164)
+    assert (games[0]["pi"][0] > 0).sum() > 1
+    assert (games[0]["pi"][-1] > 0).sum() == 1
+    b0.close()
+    b1.close()
+
+
+def test_eval_games_match_reference_loop():
+    from alphazero_amd import selfplay as sp
+
+    S, size, G = 7, 49, 6
+    sims_b, sims_l = 30, 40
+
+    class Shifted(ExactTorchEvaluator):
+        """a second, different 'network': the same function on a shifted key"""
+
+        def __call__(self, boards):
+            v, p = super().__call__(boards)
+            return (-v).contiguous(), p.flip(1).contiguous()
+
+    def shifted_numpy(b, player):
+        v, p = exact_eval_numpy(b)
+        return -v, p[::-1].copy()
+
+    best = sp.TreeBatch(G, S, ExactTorchEvaluator(), cpuct=4.0, eps=0.0, nodes_per_tree=600)
+    latest = sp.TreeBatch(G, S, Shifted(), cpuct=2.0, eps=0.0, nodes_per_tree=600)
+    for ply in range(2):
+        act = np.array([O.opening(size, g * 3 + 2)[ply] for g in range(G)], np.int32)
+        best.make_move(act)
+        latest.make_move(act)
+    wb, wl, dr = sp.eval_games(best, latest, sims_b, sims_l)
+    ev_b = oracle_exact_evaluator(S)
+    ev_l = O.callback_evaluator(shifted_numpy, S, log_priors=False)
+    exp = [0, 0, 0]
+    for g in range(G):
+        tb, tl = O.OracleTree(S, cpuct=4.0), O.OracleTree(S, cpuct=2.0)
+        for t in (tb, tl):
+            t.set_eps(0.0)
+            for ply in range(2):
+                t.make_move(O.opening(size, g * 3 + 2)[ply])
+        first_player = tb.player
+        if g % 2 == 0:
+            oracle_eval_game(tb, sims_b, ev_b, tl, sims_l, ev_l)
+        else:
+            oracle_eval_game(tl, sims_l, ev_l, tb, sims_b, ev_b)
+        w = tb.winner
+        assert float(best.winners()[g]) == w
+        if w == first_player:
+            exp[0 if g % 2 == 0 else 1] += 1
+        elif w == 1 - first_player:
+            exp[1 if g % 2 == 0 else 0] += 1
+        else:
+            exp[2] += 1
+    assert (wb, wl, dr) == tuple(exp)
+    best.close()
+    latest.close()
+
+
+def test_cmcts_facade_runs_reference_shaped_game(tmp_path):
+    """The drop-in facade with the reference's own call sequence (src/self_play.py:155-186),
+    a TorchScript net file as `params`, compared for record shapes and label rules."""
+    import torch
+
+    import alphazero_amd.cmcts as cmcts
+    from alphazero_amd.model import PolicyValueNet
+
+    S = 9
+    torch.manual_seed(0)
+    net = PolicyValueNet(S, conv_channels=8, front_layers=2, policy_layers=1, value_layers=1).eval()
+    path = str(tmp_path / "net.pt")
+    torch.jit.trace(net, torch.rand(1, 2, S, S)).save(path)
+    ms = []
+    for _ in range(2):
+        m = cmcts.mcts(cpuct=4.0, shape=S, nodes_per_tree=2048)
+        m.set_alpha_default()
+        m.set_threads(0)
+        m.set_params(path)
+        m.eps = 0.25
+        ms.append(m)
+    assert cmcts.test(1) == 2 and isinstance(cmcts.version(), str) and cmcts.build_timestamp()
+    dt = np.dtype([("board", "f4", (2, S, S)), ("pi", "f4", (S * S,)), ("r", "f4")])
+    data = []
+    for i in range(6):
+        for m in ms:
+            m.simulate(20)
+            pi = m.get_prob()
+            board = m.get_board()
+            assert pi.dtype == np.float32 and pi.shape == (S * S,) and abs(pi.sum() - 1) < 1e-3
+            assert board.dtype == np.float32 and board.shape == (2, S, S)
+            move = pi.argmax()
+            data.append(np.array((board, pi, -1), dtype=dt))
+            ms[0].make_move(move)
+            ms[1].make_move(move)
+    assert ms[0].move_cnt == 12 and ms[0].winner == -1 and ms[0].player == 0
+    with pytest.raises(RuntimeError, match="Invalid move"):
+        ms[0].make_move(int(np.stack(data)["pi"][0].argmax()))
+    with pytest.raises(RuntimeError, match="Invalid value"):
+        ms[0].cuda = 1
+    with pytest.raises(RuntimeError, match="Epsilon must be in range"):
+        ms[0].eps = 2
+    m = cmcts.mcts(shape=S)
+    with pytest.raises(RuntimeError, match="Predictor missing!"):
+        m.simulate(3)
+    m.set_params(path)
+    m.eps = 0.0
+    m.simulate(1)
+    with pytest.raises(RuntimeError, match="Not a distribution"):
+        m.get_prob()
+    assert "Move count: 0" in repr(m)
+    m.clear()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: MCTS simulations/sec, 15x15 gomoku @ 800 sims/move.
 
-Workload (BASELINE.json configs[1], tree-kernel isolation): 1024 concurrent
+Workload (tree-kernel isolation, the configuration the metric is quoted on): 1024 concurrent
 trees per GPU, 800 simulations per move, uniform-prior evaluator (p = 1/225,
 v = 0) computed inside the kernel, cpuct = 4, eps = 0.  One "step" = one move
 of every tree: simulate(800) -> greedy move choice -> make_move (re-rooting +
@@ -53,7 +53,7 @@ def cpu_baseline():
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 16))
-    games, plies = 8 * cores, 40
+    games, plies = 24 * cores, 50
     ev = O.uniform_evaluator(np.float32(1.0 / SIZE))
     total, secs = O.baseline_games(SHAPE, games, cores, plies, SIMS, CPUCT, ev)
     return {

@@ -1,0 +1,73 @@
+"""The N > 1 host path on CPU: two gloo ranks shard the games, gather their
+sample records and sum their counters (the only exchanges of the multi-GPU
+design; on GPUs the same calls run over RCCL)."""
+import os
+import socket
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from alphazero_amd import selfplay as sp
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_games = 7
+    lo, hi = sp.shard_range(n_games, rank, world)
+    dt = sp.sample_dtype(5)
+    # each game contributes (game index + 1) records tagged with the game index
+    recs = []
+    for g in range(lo, hi):
+        a = np.zeros(g + 1, dt)
+        a["r"] = g
+        a["pi"][:, g % 25] = 1
+        a["board"][:, 0, g % 5, 0] = 1
+        recs.append(a)
+    mine = np.concatenate(recs) if recs else np.zeros(0, dt)
+    everything = sp.gather_samples(mine)
+    counters = sp.reduce_counters([len(mine), hi - lo, rank])
+    np.save(os.path.join(out_dir, f"all_{rank}.npy"), everything)
+    np.save(os.path.join(out_dir, f"cnt_{rank}.npy"), counters)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_and_reduce(tmp_path):
+    import torch.multiprocessing as mp
+
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a0 = np.load(tmp_path / "all_0.npy")
+    a1 = np.load(tmp_path / "all_1.npy")
+    assert a0.dtype.names == ("board", "pi", "r")
+    assert np.array_equal(a0["r"], a1["r"]) and np.array_equal(a0["pi"], a1["pi"])
+    # 7 games, game g has g+1 records, rank order preserved
+    assert len(a0) == sum(range(1, 8))
+    assert a0["r"].tolist() == [float(g) for g in range(7) for _ in range(g + 1)]
+    c0, c1 = np.load(tmp_path / "cnt_0.npy"), np.load(tmp_path / "cnt_1.npy")
+    assert c0.tolist() == c1.tolist() == [28.0, 7.0, 1.0]
+
+
+def test_single_process_helpers_are_identity():
+    sys.path.insert(0, ROOT)
+    from alphazero_amd import selfplay as sp
+
+    dt = sp.sample_dtype(5)
+    a = np.zeros(3, dt)
+    assert sp.gather_samples(a) is a
+    assert sp.reduce_counters([1, 2]).tolist() == [1.0, 2.0]

@@ -69,7 +69,6 @@ struct AzParams {
     int path_cap;
     double cpuct;
     double eps;
-    int no_screen;    // 1 = skip the fp32 screening pass of select (exact fp64 pass only)
 };
 
 struct AzFusedArgs {

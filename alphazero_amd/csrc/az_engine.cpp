@@ -166,10 +166,6 @@ int az_create(az_engine **out, int device, int n_trees, int shape, int nodes_per
     P.noise = nullptr;
     P.noise_rows = 0;
     P.stamps = nullptr;
-    // fp32 screening of the PUCT arg-max is off unless AZ_SCREEN=1: on MI355X the
-    // extra pass costs more instructions than the fp64 divisions it avoids
-    P.no_screen = 1;
-    if (const char *x = getenv("AZ_SCREEN")) P.no_screen = atoi(x) == 0;
     const size_t slots = (size_t)n_trees * nodes_per_tree;
     int rc = AZ_OK;
     if (!rc) rc = dev_alloc(e, &P.nodes, slots * e->rec_bytes);

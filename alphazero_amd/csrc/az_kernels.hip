@@ -310,7 +310,10 @@ template <int E> __device__ __forceinline__ void state_move(WState &s, int a, in
     const bool f0 = (unsigned)hit != 0u, f1 = (unsigned)(hit >> 32) != 0u;
     if (f0 || f1) {
         int wp = f1 ? 1 : 0;
-        if (f0 && f1) wp = scan_order_winner(h, v, d, an, lane);
+        // (readfirstlane: a call's result lives in a vector register, and a value
+        // the compiler takes for lane-varying would turn every later search-loop
+        // branch into exec-mask code)
+        if (f0 && f1) wp = uni(scan_order_winner(h, v, d, an, lane));
         s.winner = (float)wp; // plane index of the winner (state.cpp:95-99)
     } else if (s.move_cnt == SIZE) {
         s.winner = 0.5f; // state.cpp:269-270, 100-102
@@ -348,30 +351,15 @@ __device__ __forceinline__ void write_board(const WState &s, float *dst, int lan
 }
 
 // ------------------------------------------------------------------ select
-__device__ __forceinline__ float wave_max_f32(float v)
-{
-    v = fmaxf(v, __int_as_float(dpp_i32<0xB1>(__float_as_int(v))));
-    v = fmaxf(v, __int_as_float(dpp_i32<0x4E>(__float_as_int(v))));
-    v = fmaxf(v, __int_as_float(dpp_i32<0x141>(__float_as_int(v))));
-    v = fmaxf(v, __int_as_float(dpp_i32<0x140>(__float_as_int(v))));
-    const float r0 = __int_as_float(lane_bcast_i32(__float_as_int(v), 0));
-    const float r1 = __int_as_float(lane_bcast_i32(__float_as_int(v), 16));
-    const float r2 = __int_as_float(lane_bcast_i32(__float_as_int(v), 32));
-    const float r3 = __int_as_float(lane_bcast_i32(__float_as_int(v), 48));
-    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
-}
-
-// Exact PUCT arg-max, Node::select (mcts/src/node.cpp:95-114), for the
-// elements of one wavefront: thread-local best in fp64, operation order as the
-// reference writes it.  Returns the wavefront maximum; (wl, wk) = owning lane
-// and element of the first maximum, wl = -1 if no legal action has u > -inf.
+// Per-thread part of Node::select (mcts/src/node.cpp:95-114): PUCT of this
+// thread's actions in fp64, operation order as the reference writes it, strict
+// '>' so the first maximum is kept.  `sq` = sqrt(nodeN + 1e-8).
 template <int E>
-__device__ __forceinline__ double exact_argmax(const NodeRegs<E> &nd, int node_n, unsigned occ, double cpuct, int tid,
-                                               int &wl, int &wk)
+__device__ __forceinline__ void scan_exact(const NodeRegs<E> &nd, double sq, unsigned occ, double cpuct, int tid,
+                                           double &best, int &bk)
 {
-    const double sq = __dsqrt_rn((double)node_n + 1e-8);
-    double best = -INFINITY;
-    int bk = -1;
+    best = -INFINITY;
+    bk = -1;
 #pragma unroll
     for (int k = 0; k < E; k++) {
         const int a = tid * E + k;
@@ -385,104 +373,56 @@ __device__ __forceinline__ double exact_argmax(const NodeRegs<E> &nd, int node_n
             bk = k;
         }
     }
-    const double m = wave_max_f64(best);
-    const unsigned long long mask = __ballot(bk >= 0 && best == m);
-    wl = -1;
-    wk = 0;
-    if (mask != 0ull) {
-        wl = __ffsll((long long)mask) - 1;
-        wk = lane_bcast_i32(bk, wl);
-    }
-    return m;
 }
 
-// Screening pass in fp32.  Every element gets an approximation uf of its PUCT
-// value and a bound ef on |uf - u| (u = the reference's fp64 result):
-//   inputs rounded to fp32 (2^-24 each), v_rcp_f32 (1 ulp), v_sqrt_f32, and the
-//   fp32 products and sum give |uf - u| <= 11 * 2^-24 * (|Q| + |U|); the bound
-//   used is 32 * 2^-24 * (|Q| + |U|) plus 1e-36 for fp32 underflow.
-// With L = max(uf - ef) <= max u, an element with uf + ef < L cannot be the
-// arg-max (nor tie with it).  The survivors are resolved without fp64 when
-//   * there is exactly one, or
-//   * all of them have bit-identical (N, W, P): identical inputs give identical
-//     u, so the first one wins exactly as the reference's strict '>' scan;
-// otherwise, or when anything is not finite in fp32, the exact pass decides.
-// Returns true with (wl, wk) set when the screening decided.
+// The same for the root held in registers across a whole simulate() call, with
+// the loop-invariant pieces cached per action: cp = cpuct*P, np1 = (double)(N+1)
+// and q = W/N.  Each cached value is the very fp64 operation the reference
+// evaluates at this point (q is refreshed whenever W or N of the action
+// changes), so u is bit-identical; per search only one W/N division remains.
+template <int E> struct RootCache {
+    double cp[E], np1[E], q[E];
+};
 template <int E>
-__device__ __forceinline__ bool screened_argmax(const NodeRegs<E> &nd, int node_n, unsigned occ, double cpuct, int tid,
-                                                int &wl, int &wk)
+__device__ __forceinline__ void scan_root(const NodeRegs<E> &R, const RootCache<E> &C, double sq, unsigned occ,
+                                          int tid, double &best, int &bk)
 {
-    const float cf = (float)cpuct;
-    const float sf = __builtin_amdgcn_sqrtf((float)node_n + 1e-8f);
-    float up[E];
-    float lo = -INFINITY;
-    bool weird = false;
+    best = -INFINITY;
+    bk = -1;
 #pragma unroll
     for (int k = 0; k < E; k++) {
         const int a = tid * E + k;
         const bool valid = (a < SIZE) && !((occ >> k) & 1u);
-        const int n = nd.n[k];
-        const float tf = (cf * (float)nd.p[k]) * sf;
-        float uf = tf, mag = fabsf(tf);
-        if (n != 0) {
-            const float qf = (float)nd.w[k] * __builtin_amdgcn_rcpf((float)n);
-            const float e2 = tf * __builtin_amdgcn_rcpf((float)(n + 1));
-            uf = qf + e2;
-            mag = fabsf(qf) + fabsf(e2);
+        const double t = C.cp[k] * sq;
+        double u = t;
+        if (R.n[k] != 0) u = C.q[k] + t / C.np1[k];
+        if (valid && u > best) {
+            best = u;
+            bk = k;
         }
-        const float ef = mag * 0x1p-19f + 1e-36f;
-        weird |= valid && !(mag < INFINITY);
-        if (valid) lo = fmaxf(lo, uf - ef);
-        up[k] = valid ? uf + ef : -INFINITY;
     }
-    if (__any(weird)) return false;
-    const float L = wave_max_f32(lo);
-    // candidates, in action order
-    int fk = E, ncand_lane = 0;
-#pragma unroll
-    for (int k = E - 1; k >= 0; k--)
-        if (up[k] >= L && up[k] > -INFINITY) { fk = k; ncand_lane++; }
-    const unsigned long long lanes = __ballot(fk < E);
-    if (lanes == 0ull) { wl = -1; wk = 0; return true; } // no legal action at all
-    wl = __ffsll((long long)lanes) - 1;
-    wk = lane_bcast_i32(fk, wl);
-    // one candidate in one lane: decided
-    const unsigned long long multi = __ballot(ncand_lane > 1);
-    if (multi == 0ull && (lanes & (lanes - 1)) == 0ull) return true;
-    // several: decided only if all carry the first one's exact inputs
-    int n0 = 0;
-    double w0 = 0., p0 = 0.;
-#pragma unroll
-    for (int k = 0; k < E; k++)
-        if (k == wk) { n0 = nd.n[k]; w0 = nd.w[k]; p0 = nd.p[k]; }
-    n0 = lane_bcast_i32(n0, wl);
-    const long long wb = __double_as_longlong(lane_bcast_f64(w0, wl));
-    const long long pb = __double_as_longlong(lane_bcast_f64(p0, wl));
-    bool differs = false;
-#pragma unroll
-    for (int k = 0; k < E; k++)
-        if (up[k] >= L && up[k] > -INFINITY)
-            differs |= nd.n[k] != n0 || __double_as_longlong(nd.w[k]) != wb || __double_as_longlong(nd.p[k]) != pb;
-    return !__any(differs);
 }
 
-// Node::select (mcts/src/node.cpp:85-124) over a group of WPT wavefronts.
-// `slots`/`phase`: double-buffered LDS exchange (unused when WPT == 1).
+// Arg-max over the group of WPT wavefronts from the per-thread results:
+// DPP max reduction + ballot inside a wavefront, then (WPT > 1) one
+// double-buffered LDS exchange; wavefront order = action order, so the first
+// strict maximum wins exactly as in the reference's scan.
 template <int WPT, int E>
-__device__ __forceinline__ Pick select_pick(const NodeRegs<E> &nd, int node_n, unsigned occ, double cpuct, int tid,
-                                            Slot *slots, int &phase, bool screen = false)
+__device__ __forceinline__ Pick finish_pick(double best, int bk, const NodeRegs<E> &nd, int tid, Slot *slots,
+                                            int &phase)
 {
+    // (tid >> 6 rather than a literal 0 for WPT == 1 on purpose: a pick the compiler
+    // can prove wave-uniform turns the search loop into scalar branches, and with one
+    // wavefront per SIMD the taken branches cost more than the exec-masked
+    // fall-through code: 7900 vs 6900 cycles per search measured on MI355X)
     const int lane = tid & 63, wave = tid >> 6;
-    int wl = -1, wk = 0;
-    double m = 0.;
-    bool decided = false;
-    if constexpr (WPT == 1) {
-        if (screen) decided = screened_argmax<E>(nd, node_n, occ, cpuct, tid, wl, wk);
-    }
-    if (!decided) m = exact_argmax<E>(nd, node_n, occ, cpuct, tid, wl, wk);
+    const double m = wave_max_f64(best);
+    const unsigned long long mask = __ballot(bk >= 0 && best == m);
     Pick pk;
     pk.a = -1; pk.n = 0; pk.link = 0; pk.w = 0.;
-    if (wl >= 0) {
+    if (mask != 0ull) {
+        const int wl = __ffsll((long long)mask) - 1;
+        const int wk = lane_bcast_i32(bk, wl);
         int my_n = 0, my_link = 0;
         double my_w = 0.;
 #pragma unroll
@@ -505,7 +445,7 @@ __device__ __forceinline__ Pick select_pick(const NodeRegs<E> &nd, int node_n, u
         out.a = -1; out.n = 0; out.link = 0; out.w = 0.;
         double bm = -INFINITY;
 #pragma unroll
-        for (int w = 0; w < WPT; w++) { // wavefront order = action order: first strict maximum wins
+        for (int w = 0; w < WPT; w++) {
             const int aw = sl[w].a;
             const double mw = sl[w].m;
             if (aw >= 0 && (out.a < 0 || mw > bm)) {
@@ -515,6 +455,26 @@ __device__ __forceinline__ Pick select_pick(const NodeRegs<E> &nd, int node_n, u
         phase ^= 1;
         return out;
     }
+}
+
+// Node::select (mcts/src/node.cpp:85-124) on a node loaded from the pool
+template <int WPT, int E>
+__device__ __forceinline__ Pick select_pick(const NodeRegs<E> &nd, double sq, unsigned occ, double cpuct, int tid,
+                                            Slot *slots, int &phase)
+{
+    double best;
+    int bk;
+    scan_exact<E>(nd, sq, occ, cpuct, tid, best, bk);
+    return finish_pick<WPT, E>(best, bk, nd, tid, slots, phase);
+}
+
+// sqrt(nodeN + 1e-8) (node.cpp:106,108): a table of the same fp64 operation for
+// the first SQ_TAB values (nodeN is an integer), the operation itself beyond
+constexpr int SQ_TAB = 2048;
+__device__ __forceinline__ double sqrt_node_n(int node_n, const double *tab)
+{
+    if (tab != nullptr && node_n < SQ_TAB) return tab[node_n];
+    return __dsqrt_rn((double)node_n + 1e-8);
 }
 
 // ------------------------------------------------------ in-kernel evaluators
@@ -542,7 +502,7 @@ __device__ __forceinline__ float evaluate(const AzFusedArgs &A, const WState &s,
     for (int o = 1; o < 64; o <<= 1) hk ^= (unsigned long long)__shfl_xor((long long)hk, o);
     const unsigned long long key = A.hash_seed ^ hk;
     const unsigned long long hv = mix64(key ^ 0x9e3779b97f4a7c15ull);
-    const float value = (float)((int)(hv & 0xFFFF) - 32768) / 32768.0f;
+    const float value = unif((float)((int)(hv & 0xFFFF) - 32768) / 32768.0f); // same in every lane
 #pragma unroll
     for (int k = 0; k < E; k++) {
         const int a = tid * E + k;
@@ -557,6 +517,12 @@ template <int E>
 __device__ __forceinline__ void mix_prior(const AzParams &P, const float (&pr)[E], bool is_log, int noise_row,
                                           int tid, double (&out)[E])
 {
+    if (P.eps == 0. && P.noise == nullptr && !is_log) {
+        // (1-0)*p + 0*0 = p: the mix is the identity, skip its arithmetic
+#pragma unroll
+        for (int k = 0; k < E; k++) out[k] = (tid * E + k < SIZE) ? (double)pr[k] : 0.;
+        return;
+    }
     const double prior_eps = 1. - P.eps;
     double nz[E];
 #pragma unroll
@@ -651,7 +617,10 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
     __shared__ double s_w1[PATH_SPILL];
     PathRegs path = {0, 0, 0, 0};
     __shared__ Slot s_slots[2 * WPT];
+    __shared__ double s_sqrt[SQ_TAB];
     int phase = 0;
+    for (int i = tid; i < SQ_TAB; i += T) s_sqrt[i] = __dsqrt_rn((double)i + 1e-8);
+    __syncthreads();
 
     WState root_state;
     load_state<E>(P, tree, tid, root_state);
@@ -664,10 +633,17 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
     unsigned long long n_sims = 0, n_exp = 0, n_term = 0, n_sel = 0;
 
     NodeRegs<E> R;
+    RootCache<E> C;
     int root_n = 0;
     if (root >= 0) {
         load_node<E>(P, tree, root, tid, false, R); // a root is always materialised
         root_n = uni(Tr->root_n);
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            C.cp[k] = P.cpuct * R.p[k];
+            C.np1[k] = (double)(R.n[k] + 1);
+            C.q[k] = R.n[k] != 0 ? R.w[k] / (double)R.n[k] : 0.;
+        }
     }
     // The root registers must be complete BEFORE the search loop: otherwise the
     // compiler guards their first use inside the loop with s_waitcnt vmcnt(0),
@@ -701,7 +677,10 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             if (P.noise != nullptr) noise_row++;
             st_f64<E>(rec_ptr(P, tree, slot) + OFF_P, tid, R.p);
 #pragma unroll
-            for (int k = 0; k < E; k++) { R.n[k] = 0; R.link[k] = 0; R.w[k] = 0.; }
+            for (int k = 0; k < E; k++) {
+                R.n[k] = 0; R.link[k] = 0; R.w[k] = 0.;
+                C.cp[k] = P.cpuct * R.p[k]; C.np1[k] = 1.; C.q[k] = 0.;
+            }
             root_n = 0;
             root = slot;
             n_exp++; n_sims++;
@@ -711,15 +690,23 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
 
         // level 0: the root, in registers
         STAMP(7);
-        Pick pk = select_pick<WPT, E>(R, root_n, s.occ, P.cpuct, tid, s_slots, phase, P.no_screen == 0);
+        Pick pk;
+        {
+            double best;
+            int bk;
+            scan_root<E>(R, C, sqrt_node_n(root_n, s_sqrt), s.occ, tid, best, bk);
+            pk = finish_pick<WPT, E>(best, bk, R, tid, s_slots, phase);
+        }
         STAMP(0);
         if (pk.a < 0) { err = AZ_ERR_NO_ACTION; break; }
         n_sel++;
         const int root_a = pk.a;
+        const bool root_owner = tid == root_a / E;
 #pragma unroll
         for (int k = 0; k < E; k++)
-            if (tid == root_a / E && k == root_a % E) {
+            if (root_owner && k == root_a % E) {
                 R.n[k] += 1;
+                C.np1[k] += 1.;
                 R.w[k] -= 1.; // virtual loss (node.cpp:118)
             }
         root_n += 1;
@@ -777,7 +764,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             __builtin_amdgcn_s_waitcnt(0x0F70);
             STAMP(2);
 #endif
-            pk = select_pick<WPT, E>(nd, nn, s.occ, P.cpuct, tid, s_slots, phase, P.no_screen == 0);
+            pk = select_pick<WPT, E>(nd, sqrt_node_n(nn, s_sqrt), s.occ, P.cpuct, tid, s_slots, phase);
             STAMP(3);
             if (pk.a < 0) { err = AZ_ERR_NO_ACTION; break; }
             n_sel++;
@@ -826,9 +813,14 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
                 reinterpret_cast<double *>(rec_ptr(P, tree, node) + OFF_W)[act] = w1 + ((double)value + 1.);
             value = -value;
         }
+        if (root_owner) { // the one W/N division of this search
 #pragma unroll
-        for (int k = 0; k < E; k++)
-            if (tid == root_a / E && k == root_a % E) R.w[k] += (double)value + 1.;
+            for (int k = 0; k < E; k++)
+                if (k == root_a % E) {
+                    R.w[k] += (double)value + 1.;
+                    C.q[k] = R.w[k] / (double)R.n[k];
+                }
+        }
         n_sims++;
         STAMP(6);
     }
@@ -877,7 +869,7 @@ __global__ __launch_bounds__(64) void k_select(AzParams P, float *d_boards, int 
         const bool fresh = nn == 0 && cur != root; // a root is always materialised
         NodeRegs<E> nd;
         load_node<E>(P, tree, cur, lane, fresh, nd);
-        const Pick pk = select_pick<1, E>(nd, nn, s.occ, P.cpuct, lane, nullptr, phase, P.no_screen == 0);
+        const Pick pk = select_pick<1, E>(nd, sqrt_node_n(nn, nullptr), s.occ, P.cpuct, lane, nullptr, phase);
         if (pk.a < 0) { err = AZ_ERR_NO_ACTION; break; }
         n_sel++;
         char *rec = rec_ptr(P, tree, cur);

@@ -218,12 +218,3 @@ def test_clear_and_reuse():
     c2, n2 = eng.get_counts()
     assert np.array_equal(c1, c2) and np.array_equal(n1, n2)
     eng.close()
-
-
-def test_screened_select_agrees(monkeypatch):
-    # same searches with the optional fp32 screening pass of select switched on:
-    # it may only ever skip work, never change a decision
-    monkeypatch.setenv("AZ_SCREEN", "1")
-    _play_fused(15, B=4, sims=300, plies=4, ev_kind="hash", eps=0.25, cpuct=4.0)
-    _play_fused(15, B=4, sims=300, plies=4, ev_kind="uniform", eps=0.0, cpuct=4.0)
-    _play_fused(7, B=6, sims=150, plies=49, ev_kind="hash", eps=0.0, cpuct=2.0)

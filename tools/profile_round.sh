@@ -1,0 +1,23 @@
+#!/bin/bash
+# Profiles `bench.py --no-cpu-baseline` on the GPU box: one kernel-trace pass and
+# separate counter passes (never combined with a trace domain), then condenses
+# them into profiles/<tag>_*.  Usage: tools/profile_round.sh <tag>
+set -e
+tag=${1:-r01}
+cd "$(dirname "$0")/.."
+out=gpurun_out/prof_$tag
+mkdir -p "$out"
+export TMPDIR=/tmp
+B="python3 bench.py --no-cpu-baseline --steps 6 --warmup 2"
+timeout -k 10 170 rocprofv3 --kernel-trace --stats -d "$out/stats" -o s --output-format csv -- $B > "$out/stats.log" 2>&1
+echo stats done
+timeout -s KILL 170 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY -d "$out/pmc_sq" -o p --output-format csv -- $B > "$out/pmc_sq.log" 2>&1
+echo sq done
+timeout -s KILL 170 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS -d "$out/pmc_sq2" -o p --output-format csv -- $B > "$out/pmc_sq2.log" 2>&1
+echo sq2 done
+timeout -s KILL 170 rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" -o p --output-format csv -- $B > "$out/pmc_fetch.log" 2>&1
+echo fetch done
+timeout -s KILL 170 rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_write" -o p --output-format csv -- $B > "$out/pmc_write.log" 2>&1
+echo write done
+python3 tools/summarize_prof.py "$tag" "$out/stats" "$out/pmc_sq" "$out/pmc_sq2" "$out/pmc_fetch" "$out/pmc_write"
+cp profiles/${tag}_kernel_stats.csv profiles/${tag}_pmc.json profiles/traffic.json "$out/" 2>/dev/null || true

@@ -4,7 +4,8 @@
     python3 tools/summarize_prof.py <tag> <stats_dir> [<pmc_dir> ...]
 
 Writes profiles/<tag>_kernel_stats.csv (copy of rocprofv3's *_kernel_stats.csv)
-and profiles/<tag>_pmc.json: per kernel and counter, the mean over dispatches.
+and profiles/<tag>_pmc.json: per kernel and counter, the mean over dispatches;
+when the fused search kernel has both HBM counters, also profiles/traffic.json.
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; on gfx950 FETCH_SIZE
 counts 64 B per 128-B request for wide coalesced reads, so the derived
 `hbm_read_bytes` doubles it (MI355X_MICROARCH.md, HBM section).
@@ -44,6 +45,12 @@ def main():
     for k, o in out.items():
         if "hbm_bytes_per_launch" in o:
             print(k, "hbm bytes/launch", o["hbm_bytes_per_launch"])
+            if "k_simulate_fused" in k:
+                # the figure bench.py reports as roofline.traffic
+                with open(os.path.join(root, "traffic.json"), "w") as f:
+                    json.dump({"kernel": k, "source": f"{tag}_pmc.json",
+                               "hbm_read_bytes": o["hbm_read_bytes"], "hbm_write_bytes": o["hbm_write_bytes"],
+                               "hbm_bytes_per_launch": o["hbm_bytes_per_launch"]}, f, indent=1)
 
 
 if __name__ == "__main__":

@@ -381,8 +381,21 @@ __device__ __forceinline__ void scan_exact(const NodeRegs<E> &nd, double sq, uns
 // evaluates at this point (q is refreshed whenever W or N of the action
 // changes), so u is bit-identical; per search only one W/N division remains.
 template <int E> struct RootCache {
-    double cp[E], np1[E], q[E];
+    double cp[E], np1[E], q[E], rinv[E];
 };
+// t / b correctly rounded, given rinv = RN(1/b): product, then two
+// residual corrections (Markstein).  The first correction makes the quotient
+// faithful, the second one rounds it correctly when b's significand is not all
+// ones; b is a small integer here and t = cpuct*P*sqrt(..) is far from the
+// fp64 under/overflow thresholds.  The residuals need a fused multiply-add,
+// which is why they are spelled as __fma_rn under -ffp-contract=off.
+__device__ __forceinline__ double div_by_cached(double t, double b, double rinv)
+{
+    double q = t * rinv;
+    q = __fma_rn(__fma_rn(-q, b, t), rinv, q);
+    q = __fma_rn(__fma_rn(-q, b, t), rinv, q);
+    return q;
+}
 template <int E>
 __device__ __forceinline__ void scan_root(const NodeRegs<E> &R, const RootCache<E> &C, double sq, unsigned occ,
                                           int tid, double &best, int &bk)
@@ -393,9 +406,11 @@ __device__ __forceinline__ void scan_root(const NodeRegs<E> &R, const RootCache<
     for (int k = 0; k < E; k++) {
         const int a = tid * E + k;
         const bool valid = (a < SIZE) && !((occ >> k) & 1u);
-        const double t = C.cp[k] * sq;
-        double u = t;
-        if (R.n[k] != 0) u = C.q[k] + t / C.np1[k];
+        // No N == 0 branch: there q = 0 and np1 = 1, and 0 + t/1 is t itself
+        // (t >= 0), so the one expression serves both cases of node.cpp:105-108
+        // and the four divisions of a thread overlap instead of running as
+        // four separate masked blocks.
+        const double u = C.q[k] + div_by_cached(C.cp[k] * sq, C.np1[k], C.rinv[k]);
         if (valid && u > best) {
             best = u;
             bk = k;
@@ -642,6 +657,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
         for (int k = 0; k < E; k++) {
             C.cp[k] = P.cpuct * R.p[k];
             C.np1[k] = (double)(R.n[k] + 1);
+            C.rinv[k] = 1. / C.np1[k];
             C.q[k] = R.n[k] != 0 ? R.w[k] / (double)R.n[k] : 0.;
         }
     }
@@ -679,7 +695,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
 #pragma unroll
             for (int k = 0; k < E; k++) {
                 R.n[k] = 0; R.link[k] = 0; R.w[k] = 0.;
-                C.cp[k] = P.cpuct * R.p[k]; C.np1[k] = 1.; C.q[k] = 0.;
+                C.cp[k] = P.cpuct * R.p[k]; C.np1[k] = 1.; C.rinv[k] = 1.; C.q[k] = 0.;
             }
             root_n = 0;
             root = slot;
@@ -813,12 +829,13 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
                 reinterpret_cast<double *>(rec_ptr(P, tree, node) + OFF_W)[act] = w1 + ((double)value + 1.);
             value = -value;
         }
-        if (root_owner) { // the one W/N division of this search
+        if (root_owner) { // the two divisions of this search: W/N and 1/(N+1)
 #pragma unroll
             for (int k = 0; k < E; k++)
                 if (k == root_a % E) {
                     R.w[k] += (double)value + 1.;
                     C.q[k] = R.w[k] / (double)R.n[k];
+                    C.rinv[k] = 1. / C.np1[k];
                 }
         }
         n_sims++;

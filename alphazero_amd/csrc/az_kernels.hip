@@ -86,6 +86,11 @@ struct Slot { // LDS exchange record of one wavefront
 };
 
 // ---------------------------------------------------------------- utilities
+// Branch hints.  With one wavefront per SIMD a taken branch costs about 33
+// cycles and a fall-through one about 13 (measured, tools/probes/issue_probe.hip),
+// so rare blocks should be laid out off the straight path.
+#define AZ_LIKELY(x) __builtin_expect(!!(x), 1)
+#define AZ_UNLIKELY(x) __builtin_expect(!!(x), 0)
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float unif(float v)
 {
@@ -287,7 +292,7 @@ template <int E> __device__ __forceinline__ void state_move(WState &s, int a, in
     if (tid == a / E) s.occ |= 1u << (a % E);
     s.player = s.player ? 0 : 1; // state.cpp:89
     s.move_cnt += 1;
-    if (s.move_cnt < 9) return;  // state.cpp:158-159
+    if (AZ_UNLIKELY(s.move_cnt < 9)) return;  // state.cpp:158-159
     // five-in-a-row windows anchored at this lane's row: bit c of
     //   h : (r,c..c+4)   v : (r..r+4,c)   d : (r+i,c+i)   an : (r+i,c-i)
     // rows r+1..r+4 come from the next lanes: DPP wave_shl:1 (lane i reads lane
@@ -308,14 +313,14 @@ template <int E> __device__ __forceinline__ void state_move(WState &s, int a, in
     an &= row < S ? ((1u << (S - row)) - 1u) : 0u;
     const unsigned long long hit = __ballot((h | v | d | an) != 0u);
     const bool f0 = (unsigned)hit != 0u, f1 = (unsigned)(hit >> 32) != 0u;
-    if (f0 || f1) {
+    if (AZ_UNLIKELY(f0 || f1)) {
         int wp = f1 ? 1 : 0;
         // (readfirstlane: a call's result lives in a vector register, and a value
         // the compiler takes for lane-varying would turn every later search-loop
         // branch into exec-mask code)
-        if (f0 && f1) wp = uni(scan_order_winner(h, v, d, an, lane));
+        if (AZ_UNLIKELY(f0 && f1)) wp = uni(scan_order_winner(h, v, d, an, lane));
         s.winner = (float)wp; // plane index of the winner (state.cpp:95-99)
-    } else if (s.move_cnt == SIZE) {
+    } else if (AZ_UNLIKELY(s.move_cnt == SIZE)) {
         s.winner = 0.5f; // state.cpp:269-270, 100-102
     }
 }
@@ -435,7 +440,7 @@ __device__ __forceinline__ Pick finish_pick(double best, int bk, const NodeRegs<
     const unsigned long long mask = __ballot(bk >= 0 && best == m);
     Pick pk;
     pk.a = -1; pk.n = 0; pk.link = 0; pk.w = 0.;
-    if (mask != 0ull) {
+    if (AZ_LIKELY(mask != 0ull)) {
         const int wl = __ffsll((long long)mask) - 1;
         const int wk = lane_bcast_i32(bk, wl);
         int my_n = 0, my_link = 0;
@@ -488,7 +493,7 @@ __device__ __forceinline__ Pick select_pick(const NodeRegs<E> &nd, double sq, un
 constexpr int SQ_TAB = 2048;
 __device__ __forceinline__ double sqrt_node_n(int node_n, const double *tab)
 {
-    if (tab != nullptr && node_n < SQ_TAB) return tab[node_n];
+    if (AZ_LIKELY(tab != nullptr && node_n < SQ_TAB)) return tab[node_n];
     return __dsqrt_rn((double)node_n + 1e-8);
 }
 
@@ -502,10 +507,11 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x)
 }
 
 // value (uniform) and this thread's linear priors for the position `s`
-template <int E>
+// EVAL: AZ_EVAL_UNIFORM / AZ_EVAL_HASH compiled in, or -1 = A.eval_kind decides.
+template <int E, int EVAL = -1>
 __device__ __forceinline__ float evaluate(const AzFusedArgs &A, const WState &s, int tid, float (&pr)[E])
 {
-    if (A.eval_kind == AZ_EVAL_UNIFORM) {
+    if (EVAL == AZ_EVAL_UNIFORM || (EVAL < 0 && A.eval_kind == AZ_EVAL_UNIFORM)) {
 #pragma unroll
         for (int k = 0; k < E; k++) pr[k] = (tid * E + k < SIZE) ? A.const_prior : 0.f;
         return A.const_value;
@@ -528,11 +534,13 @@ __device__ __forceinline__ float evaluate(const AzFusedArgs &A, const WState &s,
 }
 
 // Node::set_prior (mcts/src/node.cpp:38-45): P = (1-eps)*prior + eps*noise.
-template <int E>
+// MIX: 0 = the mix is known to be the identity (eps == 0, no table, linear
+// priors), 1 = general, -1 = decided at run time.
+template <int E, int MIX = -1>
 __device__ __forceinline__ void mix_prior(const AzParams &P, const float (&pr)[E], bool is_log, int noise_row,
                                           int tid, double (&out)[E])
 {
-    if (P.eps == 0. && P.noise == nullptr && !is_log) {
+    if (MIX == 0 || (MIX < 0 && P.eps == 0. && P.noise == nullptr && !is_log)) {
         // (1-0)*p + 0*0 = p: the mix is the identity, skip its arithmetic
 #pragma unroll
         for (int k = 0; k < E; k++) out[k] = (tid * E + k < SIZE) ? (double)pr[k] : 0.;
@@ -579,7 +587,7 @@ __device__ __forceinline__ void path_get(const PathRegs &pr, int d, int &node, i
 // pops the top of the tree's free stack (caller has checked free_top > 0)
 __device__ __forceinline__ int pop_free(const AzParams &P, size_t tbase, int &free_top, int &batch, int &pos, int tid)
 {
-    if (pos == 64) { // refill: lane j takes the j-th entry below the top
+    if (AZ_UNLIKELY(pos == 64)) { // refill: lane j takes the j-th entry below the top
         const int lane = tid & 63;
         const int idx = free_top - 1 - lane;
         batch = idx >= 0 ? P.free_stack[tbase + idx] : -1;
@@ -613,7 +621,9 @@ __device__ __forceinline__ int pop_free(const AzParams &P, size_t tbase, int &fr
 // separately rounded fp64 operations, kept as such: w1 = W - 1.0 at select,
 // W = w1 + (value + 1.0) at backup; only the final W is stored because no other
 // search of this tree can observe the intermediate.
-template <int WPT>
+// EVAL / MIX: see evaluate() and mix_prior(); the launcher picks the instance,
+// so the evaluator and noise tests leave the search loop.
+template <int WPT, int EVAL, int MIX>
 __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFusedArgs A)
 {
     constexpr int T = 64 * WPT;
@@ -673,24 +683,24 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
 
     int worker_left = 0;
     for (int i = 0; i < A.n_total && err == 0; ++i) {
-        if (worker_left == 0) { // new worker, new generator (cmcts.cpp:132-133)
+        if (AZ_UNLIKELY(worker_left == 0)) { // new worker, new generator (cmcts.cpp:132-133)
             noise_row = 0;
             worker_left = A.per_worker > 0 ? A.per_worker : A.n_total;
         }
         worker_left--;
         WState s = root_state;
 
-        if (root < 0) {
+        if (AZ_UNLIKELY(root < 0)) {
             // first search on a fresh root only expands it (cmcts.cpp:190-243)
             if (free_top == 0) { err = AZ_ERR_POOL_FULL; break; }
-            if (P.noise != nullptr && noise_row >= P.noise_rows) { err = AZ_ERR_NOISE_ROWS; break; }
+            if (MIX != 0 && P.noise != nullptr && noise_row >= P.noise_rows) { err = AZ_ERR_NOISE_ROWS; break; }
             const int slot = pop_free(P, tbase, free_top, fs_batch, fs_pos, tid);
             if (tid == 0) { P.order[tbase + n_order] = slot; P.parent[tbase + slot] = -1; }
             n_order++;
             float pr[E];
-            (void)evaluate<E>(A, s, tid, pr);
-            mix_prior<E>(P, pr, false, noise_row, tid, R.p);
-            if (P.noise != nullptr) noise_row++;
+            (void)evaluate<E, EVAL>(A, s, tid, pr);
+            mix_prior<E, MIX>(P, pr, false, noise_row, tid, R.p);
+            if (MIX != 0 && P.noise != nullptr) noise_row++;
             st_f64<E>(rec_ptr(P, tree, slot) + OFF_P, tid, R.p);
 #pragma unroll
             for (int k = 0; k < E; k++) {
@@ -714,7 +724,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             pk = finish_pick<WPT, E>(best, bk, R, tid, s_slots, phase);
         }
         STAMP(0);
-        if (pk.a < 0) { err = AZ_ERR_NO_ACTION; break; }
+        if (AZ_UNLIKELY(pk.a < 0)) { err = AZ_ERR_NO_ACTION; break; }
         n_sel++;
         const int root_a = pk.a;
         const bool root_owner = tid == root_a / E;
@@ -743,22 +753,22 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             if (cur >= 0) load_node<E>(P, tree, cur, tid, fresh, nd);
             state_move<E>(s, pk.a, tid);
             STAMP(1);
-            if (s.winner != -1.f) { // cmcts.cpp:253-267: no node for a finished game
+            if (AZ_UNLIKELY(s.winner != -1.f)) { // cmcts.cpp:253-267: no node for a finished game
                 value = (s.winner == 0.f || s.winner == 1.f) ? 1.f : 0.f;
                 n_term++;
                 break;
             }
             if (cur < 0) { // Node::next_node creates the child (node.cpp:126-134), the loop expands it
-                if (free_top == 0) { err = AZ_ERR_POOL_FULL; break; }
-                if (P.noise != nullptr && noise_row >= P.noise_rows) { err = AZ_ERR_NOISE_ROWS; break; }
+                if (AZ_UNLIKELY(free_top == 0)) { err = AZ_ERR_POOL_FULL; break; }
+                if (MIX != 0 && AZ_UNLIKELY(P.noise != nullptr && noise_row >= P.noise_rows)) { err = AZ_ERR_NOISE_ROWS; break; }
                 const int slot = pop_free(P, tbase, free_top, fs_batch, fs_pos, tid);
                 if (tid == 0) { P.order[tbase + n_order] = slot; P.parent[tbase + slot] = parent_slot; }
                 n_order++;
                 float pr[E];
-                const float v = evaluate<E>(A, s, tid, pr);
+                const float v = evaluate<E, EVAL>(A, s, tid, pr);
                 double pp[E];
-                mix_prior<E>(P, pr, false, noise_row, tid, pp);
-                if (P.noise != nullptr) noise_row++;
+                mix_prior<E, MIX>(P, pr, false, noise_row, tid, pp);
+                if (MIX != 0 && P.noise != nullptr) noise_row++;
 #ifndef AZ_EXP_NOBULK
                 st_f64<E>(rec_ptr(P, tree, slot) + OFF_P, tid, pp); // statistics stay implicit zeros
 #endif
@@ -782,7 +792,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
 #endif
             pk = select_pick<WPT, E>(nd, sqrt_node_n(nn, s_sqrt), s.occ, P.cpuct, tid, s_slots, phase);
             STAMP(3);
-            if (pk.a < 0) { err = AZ_ERR_NO_ACTION; break; }
+            if (AZ_UNLIKELY(pk.a < 0)) { err = AZ_ERR_NO_ACTION; break; }
             n_sel++;
             if (fresh) { // first select on this node: materialise its statistics
                 // (from registers of their own: reusing the load targets would
@@ -810,7 +820,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             parent_a = pk.a;
             STAMP(5);
         }
-        if (err != 0) break;
+        if (AZ_UNLIKELY(err != 0)) break;
         // backup (cmcts.cpp:271-279, node.cpp:75-83): deepest first, sign flips;
         // each W word is written by the thread that owns (and later re-reads) it
         int d = depth - 1;
@@ -1198,8 +1208,20 @@ int l_simulate_fused(const AzParams &P, const AzFusedArgs &A, void *stream)
     const int wpt = pick_wpt(P, A);
     const dim3 grid(P.n_trees);
     hipStream_t st = (hipStream_t)stream;
-    if (wpt == 1) hipLaunchKernelGGL(k_simulate_fused<1>, grid, dim3(64), 0, st, P, A);
-    else hipLaunchKernelGGL(k_simulate_fused<WPT_MAX>, grid, dim3(64 * WPT_MAX), 0, st, P, A);
+    if (wpt != 1) {
+        hipLaunchKernelGGL((k_simulate_fused<WPT_MAX, -1, -1>), grid, dim3(64 * WPT_MAX), 0, st, P, A);
+        return launch_status();
+    }
+    const bool identity_mix = P.eps == 0. && P.noise == nullptr;
+    const bool uniform = A.eval_kind == AZ_EVAL_UNIFORM;
+    if (uniform && identity_mix)
+        hipLaunchKernelGGL((k_simulate_fused<1, AZ_EVAL_UNIFORM, 0>), grid, dim3(64), 0, st, P, A);
+    else if (uniform)
+        hipLaunchKernelGGL((k_simulate_fused<1, AZ_EVAL_UNIFORM, 1>), grid, dim3(64), 0, st, P, A);
+    else if (identity_mix)
+        hipLaunchKernelGGL((k_simulate_fused<1, AZ_EVAL_HASH, 0>), grid, dim3(64), 0, st, P, A);
+    else
+        hipLaunchKernelGGL((k_simulate_fused<1, AZ_EVAL_HASH, 1>), grid, dim3(64), 0, st, P, A);
     return launch_status();
 }
 int l_select(const AzParams &P, float *d_boards, int *d_leaf_kind, void *stream)

@@ -140,6 +140,10 @@ int az_create(az_engine **out, int device, int n_trees, int shape, int nodes_per
     if (n_trees < 1) return fail(AZ_ERR_ARG, "n_trees must be at least 1");
     if (nodes_per_tree < 2 || nodes_per_tree > (1 << 19))
         return fail(AZ_ERR_ARG, "nodes_per_tree must be in 2..524288");
+    // the kernels address a record as <tree arena> + 32-bit byte offset
+    if ((size_t)nodes_per_tree * ops->sp * 24 > 0xFFFFFFFFull)
+        return fail(AZ_ERR_ARG, "nodes_per_tree * record size exceeds 4 GiB per tree (at most %zu slots for this shape)",
+                    (size_t)(0xFFFFFFFFull / ((size_t)ops->sp * 24)));
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(AZ_ERR_ARG, "device %d not present (%d visible)", device, ndev);

@@ -107,49 +107,67 @@ __device__ __forceinline__ double lane_bcast_f64(double v, int src_lane)
     return __hiloint2double(hi, lo);
 }
 
-template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
+// Lane permutation inside a row of 16 lanes.  Every lane has a source, so the
+// `old` operand is never used; written this way (old = 0, bound_ctrl) the
+// compiler folds the move into the consuming v_max_*_dpp.
 template <int CTRL> __device__ __forceinline__ int dpp_i32(int v)
 {
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 
-// max over the 64 lanes, result in every lane.  DPP butterflies inside each row
+// max over the 64 lanes, result wave-uniform.  DPP butterflies inside each row
 // of 16 lanes (quad_perm xor1, xor2, row_half_mirror, row_mirror), then the four
-// row results are read to scalars.  No NaN ever enters (callers keep them out).
-__device__ __forceinline__ double wave_max_f64(double v)
-{
-    v = fmax(v, dpp_f64<0xB1>(v));  // quad_perm [1,0,3,2]
-    v = fmax(v, dpp_f64<0x4E>(v));  // quad_perm [2,3,0,1]
-    v = fmax(v, dpp_f64<0x141>(v)); // row_half_mirror
-    v = fmax(v, dpp_f64<0x140>(v)); // row_mirror
-    double r0 = lane_bcast_f64(v, 0), r1 = lane_bcast_f64(v, 16);
-    double r2 = lane_bcast_f64(v, 32), r3 = lane_bcast_f64(v, 48);
-    return fmax(fmax(r0, r1), fmax(r2, r3));
-}
+// row results are read to scalars.
 __device__ __forceinline__ int wave_max_i32(int v)
 {
-    v = max(v, dpp_i32<0xB1>(v));
-    v = max(v, dpp_i32<0x4E>(v));
-    v = max(v, dpp_i32<0x141>(v));
-    v = max(v, dpp_i32<0x140>(v));
+    v = max(v, dpp_i32<0xB1>(v));  // quad_perm [1,0,3,2]
+    v = max(v, dpp_i32<0x4E>(v));  // quad_perm [2,3,0,1]
+    v = max(v, dpp_i32<0x141>(v)); // row_half_mirror
+    v = max(v, dpp_i32<0x140>(v)); // row_mirror
     int r0 = lane_bcast_i32(v, 0), r1 = lane_bcast_i32(v, 16);
     int r2 = lane_bcast_i32(v, 32), r3 = lane_bcast_i32(v, 48);
     return max(max(r0, r1), max(r2, r3));
 }
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+    v = max(v, (unsigned)dpp_i32<0xB1>((int)v));
+    v = max(v, (unsigned)dpp_i32<0x4E>((int)v));
+    v = max(v, (unsigned)dpp_i32<0x141>((int)v));
+    v = max(v, (unsigned)dpp_i32<0x140>((int)v));
+    unsigned r0 = lane_bcast_i32(v, 0), r1 = lane_bcast_i32(v, 16);
+    unsigned r2 = lane_bcast_i32(v, 32), r3 = lane_bcast_i32(v, 48);
+    return max(max(r0, r1), max(r2, r3));
+}
+
+// Lanes holding the maximum of v over the wavefront (those with `ok`), and the
+// maximum itself.  The fp64 order is mapped to an integer order (high word
+// signed, low word unsigned, both flipped for negatives) so each butterfly step
+// is one 32-bit DPP max instead of moves plus a 64-bit max: first the high
+// words, then the low words among the lanes that tie on the high word.
+// v + 0.0 folds -0.0 onto +0.0, which compare equal as doubles; no NaN enters.
+__device__ __forceinline__ unsigned long long wave_argmax_f64(double v, bool ok, double &m)
+{
+    v = v + 0.0;
+    const int hi = __double2hiint(v), lo = __double2loint(v);
+    const int sg = hi >> 31;
+    const int khi = hi ^ (sg & 0x7fffffff);
+    const unsigned klo = (unsigned)(lo ^ sg);
+    const int mhi = wave_max_i32(khi);
+    const unsigned mlo = wave_max_u32(khi == mhi ? klo : 0u);
+    const int msg = mhi >> 31;
+    m = __hiloint2double(mhi ^ (msg & 0x7fffffff), (int)mlo ^ msg);
+    return __ballot(ok && khi == mhi && klo == mlo);
+}
 
 __device__ __forceinline__ char *rec_ptr(const AzParams &P, int tree, int slot)
 {
-    return P.nodes + ((size_t)tree * P.cap + slot) * REC_BYTES;
+    // 64-bit arena base (loop-invariant) + 32-bit offset inside the tree's arena
+    // (az_create keeps cap * REC_BYTES below 4 GiB): one scalar multiply per record
+    return P.nodes + (size_t)tree * P.cap * REC_BYTES + (unsigned)slot * (unsigned)REC_BYTES;
 }
 
 // thread-blocked vector loads / stores of one per-action array of a record
-template <int E> __device__ __forceinline__ void ld_i32(const char *base, int tid, int (&out)[E])
+template <int E> __device__ __forceinline__ void ld_i32(const char *base, unsigned tid, int (&out)[E])
 {
     const int *p = reinterpret_cast<const int *>(base) + tid * E;
     if constexpr (E % 4 == 0) {
@@ -169,7 +187,7 @@ template <int E> __device__ __forceinline__ void ld_i32(const char *base, int ti
         for (int j = 0; j < E; j++) out[j] = p[j];
     }
 }
-template <int E> __device__ __forceinline__ void st_i32(char *base, int tid, const int (&in)[E])
+template <int E> __device__ __forceinline__ void st_i32(char *base, unsigned tid, const int (&in)[E])
 {
     int *p = reinterpret_cast<int *>(base) + tid * E;
     if constexpr (E % 4 == 0) {
@@ -185,7 +203,7 @@ template <int E> __device__ __forceinline__ void st_i32(char *base, int tid, con
         for (int j = 0; j < E; j++) p[j] = in[j];
     }
 }
-template <int E> __device__ __forceinline__ void ld_f64(const char *base, int tid, double (&out)[E])
+template <int E> __device__ __forceinline__ void ld_f64(const char *base, unsigned tid, double (&out)[E])
 {
     const double *p = reinterpret_cast<const double *>(base) + tid * E;
     if constexpr (E % 2 == 0) {
@@ -199,7 +217,7 @@ template <int E> __device__ __forceinline__ void ld_f64(const char *base, int ti
         for (int j = 0; j < E; j++) out[j] = p[j];
     }
 }
-template <int E> __device__ __forceinline__ void st_f64(char *base, int tid, const double (&in)[E])
+template <int E> __device__ __forceinline__ void st_f64(char *base, unsigned tid, const double (&in)[E])
 {
     double *p = reinterpret_cast<double *>(base) + tid * E;
     if constexpr (E % 2 == 0) {
@@ -359,12 +377,30 @@ __device__ __forceinline__ void write_board(const WState &s, float *dst, int lan
 // Per-thread part of Node::select (mcts/src/node.cpp:95-114): PUCT of this
 // thread's actions in fp64, operation order as the reference writes it, strict
 // '>' so the first maximum is kept.  `sq` = sqrt(nodeN + 1e-8).
+// A thread's best action so far together with the statistics the pick hands
+// on, carried through the scan by selects so that nothing has to be looked up
+// by index once the winning lane is known.
+struct Cand {
+    double u, w;
+    int k, n, link;
+};
+__device__ __forceinline__ void cand_init(Cand &c)
+{
+    c.u = -INFINITY; c.w = 0.; c.k = -1; c.n = 0; c.link = 0;
+}
+__device__ __forceinline__ void cand_take(Cand &c, bool gt, double u, int k, int n, int link, double w)
+{
+    c.u = gt ? u : c.u;
+    c.k = gt ? k : c.k;
+    c.n = gt ? n : c.n;
+    c.link = gt ? link : c.link;
+    c.w = gt ? w : c.w;
+}
 template <int E>
 __device__ __forceinline__ void scan_exact(const NodeRegs<E> &nd, double sq, unsigned occ, double cpuct, int tid,
-                                           double &best, int &bk)
+                                           Cand &c)
 {
-    best = -INFINITY;
-    bk = -1;
+    cand_init(c);
 #pragma unroll
     for (int k = 0; k < E; k++) {
         const int a = tid * E + k;
@@ -373,10 +409,7 @@ __device__ __forceinline__ void scan_exact(const NodeRegs<E> &nd, double sq, uns
         double u = t;
         if (nd.n[k] != 0)
             u = nd.w[k] / (double)nd.n[k] + t / (double)(nd.n[k] + 1);
-        if (valid && u > best) {
-            best = u;
-            bk = k;
-        }
+        cand_take(c, valid && u > c.u, u, k, nd.n[k], nd.link[k], nd.w[k]);
     }
 }
 
@@ -403,10 +436,9 @@ __device__ __forceinline__ double div_by_cached(double t, double b, double rinv)
 }
 template <int E>
 __device__ __forceinline__ void scan_root(const NodeRegs<E> &R, const RootCache<E> &C, double sq, unsigned occ,
-                                          int tid, double &best, int &bk)
+                                          int tid, Cand &c)
 {
-    best = -INFINITY;
-    bk = -1;
+    cand_init(c);
 #pragma unroll
     for (int k = 0; k < E; k++) {
         const int a = tid * E + k;
@@ -416,10 +448,7 @@ __device__ __forceinline__ void scan_root(const NodeRegs<E> &R, const RootCache<
         // and the four divisions of a thread overlap instead of running as
         // four separate masked blocks.
         const double u = C.q[k] + div_by_cached(C.cp[k] * sq, C.np1[k], C.rinv[k]);
-        if (valid && u > best) {
-            best = u;
-            bk = k;
-        }
+        cand_take(c, valid && u > c.u, u, k, R.n[k], R.link[k], R.w[k]);
     }
 }
 
@@ -428,30 +457,23 @@ __device__ __forceinline__ void scan_root(const NodeRegs<E> &R, const RootCache<
 // double-buffered LDS exchange; wavefront order = action order, so the first
 // strict maximum wins exactly as in the reference's scan.
 template <int WPT, int E>
-__device__ __forceinline__ Pick finish_pick(double best, int bk, const NodeRegs<E> &nd, int tid, Slot *slots,
-                                            int &phase)
+__device__ __forceinline__ Pick finish_pick(const Cand &c, int tid, Slot *slots, int &phase)
 {
     // (tid >> 6 rather than a literal 0 for WPT == 1 on purpose: a pick the compiler
     // can prove wave-uniform turns the search loop into scalar branches, and with one
     // wavefront per SIMD the taken branches cost more than the exec-masked
     // fall-through code: 7900 vs 6900 cycles per search measured on MI355X)
     const int lane = tid & 63, wave = tid >> 6;
-    const double m = wave_max_f64(best);
-    const unsigned long long mask = __ballot(bk >= 0 && best == m);
+    double m;
+    const unsigned long long mask = wave_argmax_f64(c.u, c.k >= 0, m);
     Pick pk;
     pk.a = -1; pk.n = 0; pk.link = 0; pk.w = 0.;
     if (AZ_LIKELY(mask != 0ull)) {
         const int wl = __ffsll((long long)mask) - 1;
-        const int wk = lane_bcast_i32(bk, wl);
-        int my_n = 0, my_link = 0;
-        double my_w = 0.;
-#pragma unroll
-        for (int k = 0; k < E; k++)
-            if (k == wk) { my_n = nd.n[k]; my_link = nd.link[k]; my_w = nd.w[k]; }
-        pk.a = (wave * 64 + wl) * E + wk;
-        pk.n = lane_bcast_i32(my_n, wl);
-        pk.link = lane_bcast_i32(my_link, wl);
-        pk.w = lane_bcast_f64(my_w, wl);
+        pk.a = (wave * 64 + wl) * E + lane_bcast_i32(c.k, wl);
+        pk.n = lane_bcast_i32(c.n, wl);
+        pk.link = lane_bcast_i32(c.link, wl);
+        pk.w = lane_bcast_f64(c.w, wl);
     }
     if constexpr (WPT == 1) {
         return pk;
@@ -482,10 +504,9 @@ template <int WPT, int E>
 __device__ __forceinline__ Pick select_pick(const NodeRegs<E> &nd, double sq, unsigned occ, double cpuct, int tid,
                                             Slot *slots, int &phase)
 {
-    double best;
-    int bk;
-    scan_exact<E>(nd, sq, occ, cpuct, tid, best, bk);
-    return finish_pick<WPT, E>(best, bk, nd, tid, slots, phase);
+    Cand c;
+    scan_exact<E>(nd, sq, occ, cpuct, tid, c);
+    return finish_pick<WPT, E>(c, tid, slots, phase);
 }
 
 // sqrt(nodeN + 1e-8) (node.cpp:106,108): a table of the same fp64 operation for
@@ -681,6 +702,8 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
     int fs_batch = 0, fs_pos = 64;
     STAMP_DECL
 
+    double sq_root = sqrt_node_n(root_n, s_sqrt); // sqrt(nodeN + 1e-8) of the root, kept one search ahead
+
     int worker_left = 0;
     for (int i = 0; i < A.n_total && err == 0; ++i) {
         if (AZ_UNLIKELY(worker_left == 0)) { // new worker, new generator (cmcts.cpp:132-133)
@@ -708,6 +731,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
                 C.cp[k] = P.cpuct * R.p[k]; C.np1[k] = 1.; C.rinv[k] = 1.; C.q[k] = 0.;
             }
             root_n = 0;
+            sq_root = sqrt_node_n(0, s_sqrt);
             root = slot;
             n_exp++; n_sims++;
             __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): noise loads into the root registers are complete
@@ -718,10 +742,9 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
         STAMP(7);
         Pick pk;
         {
-            double best;
-            int bk;
-            scan_root<E>(R, C, sqrt_node_n(root_n, s_sqrt), s.occ, tid, best, bk);
-            pk = finish_pick<WPT, E>(best, bk, R, tid, s_slots, phase);
+            Cand c;
+            scan_root<E>(R, C, sq_root, s.occ, tid, c);
+            pk = finish_pick<WPT, E>(c, tid, s_slots, phase);
         }
         STAMP(0);
         if (AZ_UNLIKELY(pk.a < 0)) { err = AZ_ERR_NO_ACTION; break; }
@@ -736,6 +759,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
                 R.w[k] -= 1.; // virtual loss (node.cpp:118)
             }
         root_n += 1;
+        sq_root = sqrt_node_n(root_n, s_sqrt); // for the next search: the table read overlaps this one
 
         int depth = 0;           // path entries below the root
         int parent_slot = root;  // node that will own the link to a new child

@@ -764,8 +764,11 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
         int depth = 0;           // path entries below the root
         int parent_slot = root;  // node that will own the link to a new child
         int parent_a = pk.a;
-        float value = 0.f;
-        for (;;) {
+        // The descent only walks; how it ended is acted upon after the loop, so the
+        // expansion's bookkeeping is not carried around the loop.
+        enum { GO = 0, TERMINAL = 1, EXPAND = 2, NO_ACTION = 3 };
+        int leaf = GO;
+        do {
             // pk = the pick made at the node above; its move is not applied yet.
             // The child's nodeN is the parent's visit count of the action minus
             // the visit that created it.  Its record is requested BEFORE the
@@ -778,71 +781,77 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             state_move<E>(s, pk.a, tid);
             STAMP(1);
             if (AZ_UNLIKELY(s.winner != -1.f)) { // cmcts.cpp:253-267: no node for a finished game
-                value = (s.winner == 0.f || s.winner == 1.f) ? 1.f : 0.f;
-                n_term++;
-                break;
-            }
-            if (cur < 0) { // Node::next_node creates the child (node.cpp:126-134), the loop expands it
-                if (AZ_UNLIKELY(free_top == 0)) { err = AZ_ERR_POOL_FULL; break; }
-                if (MIX != 0 && AZ_UNLIKELY(P.noise != nullptr && noise_row >= P.noise_rows)) { err = AZ_ERR_NOISE_ROWS; break; }
-                const int slot = pop_free(P, tbase, free_top, fs_batch, fs_pos, tid);
-                if (tid == 0) { P.order[tbase + n_order] = slot; P.parent[tbase + slot] = parent_slot; }
-                n_order++;
-                float pr[E];
-                const float v = evaluate<E, EVAL>(A, s, tid, pr);
-                double pp[E];
-                mix_prior<E, MIX>(P, pr, false, noise_row, tid, pp);
-                if (MIX != 0 && P.noise != nullptr) noise_row++;
-#ifndef AZ_EXP_NOBULK
-                st_f64<E>(rec_ptr(P, tree, slot) + OFF_P, tid, pp); // statistics stay implicit zeros
-#endif
-                if (tid == parent_a / E) {
-                    if (depth == 0) {
-#pragma unroll
-                        for (int k = 0; k < E; k++)
-                            if (k == parent_a % E) R.link[k] = slot + 1;
-                    } else {
-                        reinterpret_cast<int *>(rec_ptr(P, tree, parent_slot) + OFF_LINK)[parent_a] = slot + 1;
-                    }
-                }
-                value = -v; // cmcts.cpp:228
-                n_exp++;
-                STAMP(4);
-                break;
-            }
-#ifdef AZ_STAMPS
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            STAMP(2);
-#endif
-            pk = select_pick<WPT, E>(nd, sqrt_node_n(nn, s_sqrt), s.occ, P.cpuct, tid, s_slots, phase);
-            STAMP(3);
-            if (AZ_UNLIKELY(pk.a < 0)) { err = AZ_ERR_NO_ACTION; break; }
-            n_sel++;
-            if (fresh) { // first select on this node: materialise its statistics
-                // (from registers of their own: reusing the load targets would
-                // make later loads wait for these stores to complete)
-                NodeRegs<E> z;
-#pragma unroll
-                for (int k = 0; k < E; k++) {
-                    z.n[k] = (tid == pk.a / E && k == pk.a % E) ? 1 : 0;
-                    z.link[k] = 0;
-                    z.w[k] = 0.;
-                }
-#ifndef AZ_EXP_NOBULK
-                store_stats<E>(P, tree, cur, tid, z);
-#endif
-            } else if (tid == pk.a / E) {
-                reinterpret_cast<int *>(rec_ptr(P, tree, cur) + OFF_N)[pk.a] = pk.n + 1;
-            }
-            if (__builtin_expect(depth >= 64, 0)) {
-                s_node[depth - 64] = cur; s_act[depth - 64] = pk.a; s_w1[depth - 64] = pk.w - 1.;
+                leaf = TERMINAL;
+            } else if (cur < 0) { // Node::next_node creates the child (node.cpp:126-134)
+                leaf = EXPAND;
             } else {
-                path_put(path, depth, cur, pk.a, pk.w - 1. /* virtual loss */, tid & 63);
+#ifdef AZ_STAMPS
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                STAMP(2);
+#endif
+                pk = select_pick<WPT, E>(nd, sqrt_node_n(nn, s_sqrt), s.occ, P.cpuct, tid, s_slots, phase);
+                STAMP(3);
+                if (AZ_UNLIKELY(pk.a < 0)) {
+                    leaf = NO_ACTION;
+                } else {
+                    n_sel++;
+                    if (fresh) { // first select on this node: materialise its statistics
+                        // (from registers of their own: reusing the load targets would
+                        // make later loads wait for these stores to complete)
+                        NodeRegs<E> z;
+#pragma unroll
+                        for (int k = 0; k < E; k++) {
+                            z.n[k] = (tid == pk.a / E && k == pk.a % E) ? 1 : 0;
+                            z.link[k] = 0;
+                            z.w[k] = 0.;
+                        }
+                        store_stats<E>(P, tree, cur, tid, z);
+                    } else if (tid == pk.a / E) {
+                        reinterpret_cast<int *>(rec_ptr(P, tree, cur) + OFF_N)[pk.a] = pk.n + 1;
+                    }
+                    if (AZ_UNLIKELY(depth >= 64)) {
+                        s_node[depth - 64] = cur; s_act[depth - 64] = pk.a; s_w1[depth - 64] = pk.w - 1.;
+                    } else {
+                        path_put(path, depth, cur, pk.a, pk.w - 1. /* virtual loss */, tid & 63);
+                    }
+                    depth++;
+                    parent_slot = cur;
+                    parent_a = pk.a;
+                    STAMP(5);
+                }
             }
-            depth++;
-            parent_slot = cur;
-            parent_a = pk.a;
-            STAMP(5);
+        } while (leaf == GO);
+
+        float value = 0.f;
+        if (AZ_UNLIKELY(leaf == TERMINAL)) {
+            value = (s.winner == 0.f || s.winner == 1.f) ? 1.f : 0.f;
+            n_term++;
+        } else if (AZ_LIKELY(leaf == EXPAND)) { // the new child is expanded at once (cmcts.cpp:190-243)
+            if (AZ_UNLIKELY(free_top == 0)) { err = AZ_ERR_POOL_FULL; break; }
+            if (MIX != 0 && AZ_UNLIKELY(P.noise != nullptr && noise_row >= P.noise_rows)) { err = AZ_ERR_NOISE_ROWS; break; }
+            const int slot = pop_free(P, tbase, free_top, fs_batch, fs_pos, tid);
+            if (tid == 0) { P.order[tbase + n_order] = slot; P.parent[tbase + slot] = parent_slot; }
+            n_order++;
+            float pr[E];
+            const float v = evaluate<E, EVAL>(A, s, tid, pr);
+            double pp[E];
+            mix_prior<E, MIX>(P, pr, false, noise_row, tid, pp);
+            if (MIX != 0 && P.noise != nullptr) noise_row++;
+            st_f64<E>(rec_ptr(P, tree, slot) + OFF_P, tid, pp); // statistics stay implicit zeros
+            if (tid == parent_a / E) {
+                if (depth == 0) {
+#pragma unroll
+                    for (int k = 0; k < E; k++)
+                        if (k == parent_a % E) R.link[k] = slot + 1;
+                } else {
+                    reinterpret_cast<int *>(rec_ptr(P, tree, parent_slot) + OFF_LINK)[parent_a] = slot + 1;
+                }
+            }
+            value = -v; // cmcts.cpp:228
+            n_exp++;
+            STAMP(4);
+        } else {
+            err = AZ_ERR_NO_ACTION;
         }
         if (AZ_UNLIKELY(err != 0)) break;
         // backup (cmcts.cpp:271-279, node.cpp:75-83): deepest first, sign flips;

@@ -115,18 +115,26 @@ template <int CTRL> __device__ __forceinline__ int dpp_i32(int v)
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 
+// Row-to-row step of a wavefront reduction: row_bcast:15 hands lane 15 of each
+// row to the next row (applied to rows 1 and 3), row_bcast:31 hands lane 31 to
+// rows 2 and 3; rows outside the row mask keep `v`.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_rows_i32(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+}
+
 // max over the 64 lanes, result wave-uniform.  DPP butterflies inside each row
-// of 16 lanes (quad_perm xor1, xor2, row_half_mirror, row_mirror), then the four
-// row results are read to scalars.
+// of 16 lanes (quad_perm xor1, xor2, row_half_mirror, row_mirror), two
+// row broadcasts that gather the four row results in lane 63, one v_readlane.
 __device__ __forceinline__ int wave_max_i32(int v)
 {
     v = max(v, dpp_i32<0xB1>(v));  // quad_perm [1,0,3,2]
     v = max(v, dpp_i32<0x4E>(v));  // quad_perm [2,3,0,1]
     v = max(v, dpp_i32<0x141>(v)); // row_half_mirror
     v = max(v, dpp_i32<0x140>(v)); // row_mirror
-    int r0 = lane_bcast_i32(v, 0), r1 = lane_bcast_i32(v, 16);
-    int r2 = lane_bcast_i32(v, 32), r3 = lane_bcast_i32(v, 48);
-    return max(max(r0, r1), max(r2, r3));
+    v = max(v, dpp_rows_i32<0x142, 0xA>(v)); // row_bcast:15
+    v = max(v, dpp_rows_i32<0x143, 0xC>(v)); // row_bcast:31
+    return lane_bcast_i32(v, 63);
 }
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
 {
@@ -134,9 +142,9 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
     v = max(v, (unsigned)dpp_i32<0x4E>((int)v));
     v = max(v, (unsigned)dpp_i32<0x141>((int)v));
     v = max(v, (unsigned)dpp_i32<0x140>((int)v));
-    unsigned r0 = lane_bcast_i32(v, 0), r1 = lane_bcast_i32(v, 16);
-    unsigned r2 = lane_bcast_i32(v, 32), r3 = lane_bcast_i32(v, 48);
-    return max(max(r0, r1), max(r2, r3));
+    v = max(v, (unsigned)dpp_rows_i32<0x142, 0xA>((int)v));
+    v = max(v, (unsigned)dpp_rows_i32<0x143, 0xC>((int)v));
+    return (unsigned)lane_bcast_i32((int)v, 63);
 }
 
 // Lanes holding the maximum of v over the wavefront (those with `ok`), and the
@@ -751,13 +759,16 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
         n_sel++;
         const int root_a = pk.a;
         const bool root_owner = tid == root_a / E;
+        // the visit and the virtual loss (node.cpp:116-118) of the picked action,
+        // as additions of 0 or 1 (x + 0.0 and x - 0.0 are x for these values)
 #pragma unroll
-        for (int k = 0; k < E; k++)
-            if (root_owner && k == root_a % E) {
-                R.n[k] += 1;
-                C.np1[k] += 1.;
-                R.w[k] -= 1.; // virtual loss (node.cpp:118)
-            }
+        for (int k = 0; k < E; k++) {
+            const bool hit = root_owner && k == root_a % E;
+            const double one = hit ? 1. : 0.;
+            R.n[k] += hit ? 1 : 0;
+            C.np1[k] += one;
+            R.w[k] -= one;
+        }
         root_n += 1;
         sq_root = sqrt_node_n(root_n, s_sqrt); // for the next search: the table read overlaps this one
 

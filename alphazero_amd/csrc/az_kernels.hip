@@ -115,12 +115,25 @@ template <int CTRL> __device__ __forceinline__ int dpp_i32(int v)
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 
-// Row-to-row step of a wavefront reduction: row_bcast:15 hands lane 15 of each
-// row to the next row (applied to rows 1 and 3), row_bcast:31 hands lane 31 to
-// rows 2 and 3; rows outside the row mask keep `v`.
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_rows_i32(int v)
+// Row-to-row steps of a wavefront max reduction: row_bcast:15 hands lane 15 of
+// each row to the next row (applied to rows 1 and 3), row_bcast:31 hands lane 31
+// to rows 2 and 3; rows outside the row mask keep their value, so lane 63 ends up
+// with the maximum of the four rows.  Written as the two instructions themselves:
+// through the dpp intrinsic each step compiles to copy + move + max.  (s_nop 1:
+// a DPP operand needs two wait states after the VALU write of its source.)
+__device__ __forceinline__ int rows_max_i32(int v)
 {
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+    asm("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ unsigned rows_max_u32(unsigned v)
+{
+    asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(v));
+    return v;
 }
 
 // max over the 64 lanes, result wave-uniform.  DPP butterflies inside each row
@@ -132,9 +145,7 @@ __device__ __forceinline__ int wave_max_i32(int v)
     v = max(v, dpp_i32<0x4E>(v));  // quad_perm [2,3,0,1]
     v = max(v, dpp_i32<0x141>(v)); // row_half_mirror
     v = max(v, dpp_i32<0x140>(v)); // row_mirror
-    v = max(v, dpp_rows_i32<0x142, 0xA>(v)); // row_bcast:15
-    v = max(v, dpp_rows_i32<0x143, 0xC>(v)); // row_bcast:31
-    return lane_bcast_i32(v, 63);
+    return lane_bcast_i32(rows_max_i32(v), 63);
 }
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
 {
@@ -142,9 +153,7 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
     v = max(v, (unsigned)dpp_i32<0x4E>((int)v));
     v = max(v, (unsigned)dpp_i32<0x141>((int)v));
     v = max(v, (unsigned)dpp_i32<0x140>((int)v));
-    v = max(v, (unsigned)dpp_rows_i32<0x142, 0xA>((int)v));
-    v = max(v, (unsigned)dpp_rows_i32<0x143, 0xC>((int)v));
-    return (unsigned)lane_bcast_i32((int)v, 63);
+    return (unsigned)lane_bcast_i32((int)rows_max_u32(v), 63);
 }
 
 // Lanes holding the maximum of v over the wavefront (those with `ok`), and the
@@ -442,9 +451,10 @@ __device__ __forceinline__ double div_by_cached(double t, double b, double rinv)
     q = __fma_rn(__fma_rn(-q, b, t), rinv, q);
     return q;
 }
+// `u` keeps every action's score (-inf for an illegal one) for the next-pick hint.
 template <int E>
 __device__ __forceinline__ void scan_root(const NodeRegs<E> &R, const RootCache<E> &C, double sq, unsigned occ,
-                                          int tid, Cand &c)
+                                          int tid, Cand &c, double (&uk)[E])
 {
     cand_init(c);
 #pragma unroll
@@ -456,8 +466,54 @@ __device__ __forceinline__ void scan_root(const NodeRegs<E> &R, const RootCache<
         // and the four divisions of a thread overlap instead of running as
         // four separate masked blocks.
         const double u = C.q[k] + div_by_cached(C.cp[k] * sq, C.np1[k], C.rinv[k]);
+        uk[k] = valid ? u : -INFINITY;
         cand_take(c, valid && u > c.u, u, k, R.n[k], R.link[k], R.w[k]);
     }
+}
+
+// Pulls the lines of a node record into L2 without touching a register: each
+// lane loads one dword of "its" 128-byte line straight into a scratch LDS word
+// (LDS-DMA load) that nobody reads.  A never-selected node only has its P section.
+__device__ __forceinline__ void prefetch_record(const char *rec, int lane, bool materialised, int *lds_sink)
+{
+    static_assert(REC_BYTES % 128 == 0 && OFF_P % 128 == 0, "record sections are line-aligned");
+    constexpr int LINES = REC_BYTES / 128, P_LINE = OFF_P / 128;
+#pragma unroll
+    for (int l0 = 0; l0 < LINES; l0 += 64) {
+        const int l = l0 + lane;
+        if (l < LINES && (materialised || l >= P_LINE))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rec + (size_t)l * 128),
+                                             (__attribute__((address_space(3))) void *)lds_sink, 4, 0, 0);
+    }
+}
+
+// Hint for the next search: the runner-up of this root scan (the winner's own
+// visit lowers its score, the common sqrt factor moves all others alike).
+// Compared on the high word of the score only; a wrong hint costs nothing but
+// the prefetch.  Returns the runner-up's child link (0 = none) and visit count.
+template <int E>
+__device__ __forceinline__ void runner_up(const NodeRegs<E> &R, const Cand &c, const double (&uk)[E], int win_a,
+                                          int tid, int &link2, int &n2)
+{
+    double v2 = c.u;
+    int l2 = c.link, m2 = c.n;
+    if (tid == win_a / E) { // the winner's thread offers its best remaining action
+        v2 = -INFINITY; l2 = 0; m2 = 0;
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            const bool gt = k != win_a % E && uk[k] > v2;
+            v2 = gt ? uk[k] : v2;
+            l2 = gt ? R.link[k] : l2;
+            m2 = gt ? R.n[k] : m2;
+        }
+    }
+    const int hi = __double2hiint(v2);
+    const int khi = hi ^ ((hi >> 31) & 0x7fffffff);
+    const int mhi = wave_max_i32(khi);
+    const unsigned long long mask = __ballot(khi == mhi);
+    const int wl = __ffsll((long long)mask) - 1; // never empty: some lane holds the maximum
+    link2 = lane_bcast_i32(l2, wl);
+    n2 = lane_bcast_i32(m2, wl);
 }
 
 // Arg-max over the group of WPT wavefronts from the per-thread results:
@@ -650,6 +706,11 @@ __device__ __forceinline__ int pop_free(const AzParams &P, size_t tbase, int &fr
 // separately rounded fp64 operations, kept as such: w1 = W - 1.0 at select,
 // W = w1 + (value + 1.0) at backup; only the final W is stored because no other
 // search of this tree can observe the intermediate.
+#ifdef AZ_NO_PREFETCH
+constexpr bool PREFETCH_NEXT = false;
+#else
+constexpr bool PREFETCH_NEXT = true;
+#endif
 // EVAL / MIX: see evaluate() and mix_prior(); the launcher picks the instance,
 // so the evaluator and noise tests leave the search loop.
 template <int WPT, int EVAL, int MIX>
@@ -672,6 +733,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
     PathRegs path = {0, 0, 0, 0};
     __shared__ Slot s_slots[2 * WPT];
     __shared__ double s_sqrt[SQ_TAB];
+    __shared__ int s_sink[64]; // landing zone of the record prefetches, never read
     int phase = 0;
     for (int i = tid; i < SQ_TAB; i += T) s_sqrt[i] = __dsqrt_rn((double)i + 1e-8);
     __syncthreads();
@@ -749,10 +811,14 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
         // level 0: the root, in registers
         STAMP(7);
         Pick pk;
+        int pf_link = 0, pf_n = 0; // child of the likely next root pick
         {
             Cand c;
-            scan_root<E>(R, C, sq_root, s.occ, tid, c);
+            double uk[E];
+            scan_root<E>(R, C, sq_root, s.occ, tid, c, uk);
             pk = finish_pick<WPT, E>(c, tid, s_slots, phase);
+            if constexpr (WPT == 1 && PREFETCH_NEXT)
+                if (AZ_LIKELY(pk.a >= 0)) runner_up<E>(R, c, uk, pk.a, tid, pf_link, pf_n);
         }
         STAMP(0);
         if (AZ_UNLIKELY(pk.a < 0)) { err = AZ_ERR_NO_ACTION; break; }
@@ -833,6 +899,11 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             }
         } while (leaf == GO);
 
+        if constexpr (WPT == 1 && PREFETCH_NEXT) {
+            // fetched into L2 while this search expands and backs up, so the next
+            // search's child load does not pay the HBM latency
+            if (pf_link > 0) prefetch_record(rec_ptr(P, tree, pf_link - 1), tid, pf_n > 1, s_sink);
+        }
         float value = 0.f;
         if (AZ_UNLIKELY(leaf == TERMINAL)) {
             value = (s.winner == 0.f || s.winner == 1.f) ? 1.f : 0.f;
@@ -896,6 +967,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
         STAMP(6);
     }
     STAMP_FLUSH(tree);
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): no prefetch may land in LDS after the group has ended
 
     if (root >= 0) store_stats<E>(P, tree, root, tid, R);
     if (tid == 0) {

@@ -197,7 +197,7 @@ def main():
                 "nodes_per_tree": NODES_PER_TREE,
                 "mean_select_depth": depth_all,
                 "restarted_games": restarts,
-                "max_live_nodes_per_tree": max_used,
+                "max_live_nodes_per_tree_after_move": max_used,
             },
             "roofline": {
                 "bound": "hbm",

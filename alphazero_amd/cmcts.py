@@ -17,9 +17,10 @@ Differences that cannot be avoided:
   * `params` accepts the reference's TorchScript file path (loaded with
     torch.jit.load onto the GPU) or an evaluator object (see
     alphazero_amd.evaluator); the net is evaluated once per search step.
-  * Dirichlet noise comes from a host-generated table (numpy, seed
-    `noise_seed`, default 0 -- the reference also re-seeds its generator with
-    the default seed at every simulate() call, cmcts.cpp:132-133), not from GSL.
+  * Dirichlet noise comes from a table generated on the GPU by the engine's
+    counter-based sampler (az_fill_noise_dirichlet, seed `noise_seed`, default
+    0 -- the reference also re-seeds its generator with the default seed at
+    every simulate() call, cmcts.cpp:132-133), not from GSL.
 """
 import os
 
@@ -191,8 +192,7 @@ class mcts:
         key = (self._eng.get_alpha(), self.noise_seed)
         if self._noise_key is None or self._noise_key[:2] != key or self._noise_key[2] < rows:
             rows = max(rows, 1024)
-            rng = np.random.default_rng(self.noise_seed)
-            self._eng.set_noise_table(rng.dirichlet(np.full(self._size, key[0]), size=rows))
+            self._eng.fill_noise_dirichlet(rows, self.noise_seed)
             self._noise_key = key + (rows,)
 
     def set_noise_table(self, table):

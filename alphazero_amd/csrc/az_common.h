@@ -94,6 +94,9 @@ struct AzShapeOps {
     int (*clear)(const AzParams &, const unsigned char *d_mask, void *stream);
     int (*select_greedy)(const AzParams &, int *d_actions, void *stream);
     int (*get_counts)(const AzParams &, int *d_counts, int *d_root_n, void *stream);
+    int (*choose_moves)(const AzParams &, const double *d_u, int greedy, int *d_actions, float *d_pi,
+                        float *d_board, void *stream);
+    int (*dirichlet)(double *d_table, int rows, double alpha, unsigned long long seed, void *stream);
 };
 
 #endif

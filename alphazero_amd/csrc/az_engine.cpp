@@ -66,6 +66,7 @@ struct az_engine {
     int *d_counts = nullptr;       // [n_trees][size]
     int *d_root_n = nullptr;       // [n_trees]
     double *d_noise = nullptr;     // [rows][sp]
+    int noise_cap = 0;             // rows allocated at d_noise
     std::vector<AzTree> h_trees;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -115,6 +116,7 @@ const char *kernel_err_text(int code)
     case AZ_ERR_NO_ACTION: return "No action chosen. Incorrect behaviour";
     case AZ_ERR_NOISE_ROWS: return "noise table exhausted";
     case AZ_ERR_INVALID_MOVE: return "Invalid move";
+    case AZ_ERR_NOT_DIST: return "Not a distribution";
     default: return "kernel error";
     }
 }
@@ -365,6 +367,7 @@ int az_set_noise_table(az_engine *e, const double *noise, int rows)
         (void)hipFree(e->d_noise);
         e->d_noise = nullptr;
     }
+    e->noise_cap = 0;
     e->P.noise = nullptr;
     e->P.noise_rows = 0;
     if (rows <= 0 || !noise) return AZ_OK;
@@ -373,6 +376,7 @@ int az_set_noise_table(az_engine *e, const double *noise, int rows)
         memcpy(&padded[(size_t)r * e->sp], noise + (size_t)r * e->size, sizeof(double) * e->size);
     HIP_TRY(hipMalloc((void **)&e->d_noise, padded.size() * sizeof(double)));
     HIP_TRY(hipMemcpy(e->d_noise, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice));
+    e->noise_cap = rows;
     e->P.noise = e->d_noise;
     e->P.noise_rows = rows;
     return AZ_OK;
@@ -500,6 +504,52 @@ int az_select_greedy(az_engine *e, int *d_actions, void *stream)
     if (!e || !d_actions) return fail(AZ_ERR_ARG, "null argument");
     DeviceGuard g(e->device);
     if (e->ops->select_greedy(e->P, d_actions, stream)) return fail(AZ_ERR_HIP, "select_greedy launch failed");
+    return AZ_OK;
+}
+
+int az_choose_moves(az_engine *e, const double *d_u, int greedy, int *d_actions, float *d_pi, float *d_board,
+                    void *stream)
+{
+    if (!e || !d_actions) return fail(AZ_ERR_ARG, "null argument");
+    if (!greedy && !d_u) return fail(AZ_ERR_ARG, "sampling needs one uniform number per tree (d_u)");
+    DeviceGuard g(e->device);
+    if (e->ops->choose_moves(e->P, d_u, greedy ? 1 : 0, d_actions, d_pi, d_board, stream))
+        return fail(AZ_ERR_HIP, "choose_moves launch failed");
+    return AZ_OK;
+}
+
+int az_fill_noise_dirichlet(az_engine *e, int rows, unsigned long long seed, void *stream)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    if (rows < 1) return fail(AZ_ERR_ARG, "rows must be at least 1");
+    if (!(e->alpha > 0.)) return fail(AZ_ERR_ARG, "alpha must be positive");
+    DeviceGuard g(e->device);
+    if (rows > e->noise_cap) {
+        HIP_TRY(hipDeviceSynchronize()); // searches in flight may still read the old table
+        if (e->d_noise) (void)hipFree(e->d_noise);
+        e->d_noise = nullptr;
+        e->noise_cap = 0;
+        e->P.noise = nullptr;
+        e->P.noise_rows = 0;
+        HIP_TRY(hipMalloc((void **)&e->d_noise, (size_t)rows * e->sp * sizeof(double)));
+        e->noise_cap = rows;
+    }
+    if (e->ops->dirichlet(e->d_noise, rows, e->alpha, seed, stream)) return fail(AZ_ERR_HIP, "dirichlet launch failed");
+    e->P.noise = e->d_noise;
+    e->P.noise_rows = rows;
+    return AZ_OK;
+}
+
+int az_get_noise_table(az_engine *e, double *noise, int rows)
+{
+    if (!e || !noise) return fail(AZ_ERR_ARG, "null argument");
+    if (rows < 0 || rows > e->P.noise_rows) return fail(AZ_ERR_ARG, "the table holds %d rows", e->P.noise_rows);
+    DeviceGuard g(e->device);
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<double> padded((size_t)rows * e->sp);
+    if (rows) HIP_TRY(hipMemcpy(padded.data(), e->d_noise, padded.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int r = 0; r < rows; r++)
+        memcpy(noise + (size_t)r * e->size, &padded[(size_t)r * e->sp], sizeof(double) * e->size);
     return AZ_OK;
 }
 

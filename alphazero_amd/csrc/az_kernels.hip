@@ -1301,6 +1301,157 @@ __global__ __launch_bounds__(64) void k_get_counts(AzParams P, int *d_counts, in
     if (d_root_n != nullptr && lane == 0) d_root_n[tree] = root >= 0 ? T->root_n : -1;
 }
 
+// ------------------------------------------------- move choice + sample record
+// One move decision of self_play_game / eval_game for every active tree
+// (src/self_play.py:157-165, src/eval.py:191-193) without leaving the GPU:
+//   pi    = Cmcts::get_prob (mcts/src/cmcts.cpp:323-339): (float)((double)N/nodeN),
+//           prob_sum accumulated in index order, "Not a distribution" unless
+//           round(prob_sum*1000) == 1000;
+//   move  = pi.argmax() (first maximum) and pi := one-hot when `greedy`,
+//           else numpy.random.choice(SIZE, p=pi) for the uniform number u it is
+//           given: cdf = cumsum(p as fp64) in index order, cdf /= cdf[-1],
+//           move = number of cdf entries <= u (searchsorted, side='right');
+//   board = State::get_board (mcts/src/state.cpp:39-48): plane 0 = side to move.
+// The two running sums are sequential on purpose (one lane): their rounding is
+// part of the result.
+__global__ __launch_bounds__(64) void k_choose_moves(AzParams P, const double *d_u, int greedy, int *d_actions,
+                                                     float *d_pi, float *d_board)
+{
+    constexpr int E = EPL;
+    const int tree = blockIdx.x;
+    const int lane = threadIdx.x;
+    AzTree *T = &P.trees[tree];
+    if (uni(T->active) == 0 || uni(T->err) != 0) {
+        if (lane == 0) d_actions[tree] = -1;
+        return;
+    }
+    __shared__ float s_pi[SP];
+    __shared__ double s_cdf[SP];
+    __shared__ int s_bad;
+    const int root = uni(T->root);
+    const double node_n = root >= 0 ? (double)uni(T->root_n) : -1.; // an unexpanded root has nodeN = -1
+    int n[E];
+#pragma unroll
+    for (int k = 0; k < E; k++) n[k] = 0;
+    if (root >= 0) ld_i32<E>(rec_ptr(P, tree, root) + OFF_N, lane, n);
+    float pi[E];
+#pragma unroll
+    for (int k = 0; k < E; k++) {
+        pi[k] = (float)((double)n[k] / node_n);
+        s_pi[lane * E + k] = pi[k];
+    }
+    __syncthreads();
+    if (lane == 0) {
+        double prob_sum = 0., run = 0.;
+        for (int i = 0; i < SIZE; i++) {
+            const double p = (double)s_pi[i];
+            prob_sum += p;
+            run += p;
+            s_cdf[i] = run;
+        }
+        s_bad = round(prob_sum * 1000.) != 1000. ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_bad) {
+        if (lane == 0) { T->err = AZ_ERR_NOT_DIST; d_actions[tree] = -1; }
+        return;
+    }
+    int move;
+    if (greedy) {
+        float best = -INFINITY;
+        int bk = -1;
+#pragma unroll
+        for (int k = 0; k < E; k++)
+            if (lane * E + k < SIZE && pi[k] > best) { best = pi[k]; bk = k; }
+        double m;
+        const unsigned long long mask = wave_argmax_f64((double)best, bk >= 0, m);
+        const int wl = __ffsll((long long)mask) - 1;
+        move = wl * E + lane_bcast_i32(bk, wl);
+    } else {
+        const double u = d_u[tree];
+        const double total = s_cdf[SIZE - 1];
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            const int a = lane * E + k;
+            cnt += __popcll(__ballot(a < SIZE && s_cdf[a < SIZE ? a : 0] / total <= u));
+        }
+        move = cnt < SIZE ? cnt : SIZE - 1;
+    }
+    if (lane == 0) d_actions[tree] = move;
+    if (d_pi != nullptr) {
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            const int a = lane * E + k;
+            if (a < SIZE) d_pi[(size_t)tree * SIZE + a] = greedy ? (a == move ? 1.f : 0.f) : pi[k];
+        }
+    }
+    if (d_board != nullptr) {
+        const unsigned rb = P.rows[tree * 64 + lane];
+        const int row = lane & 31, plane = lane >> 5;
+        const int out_plane = uni(T->player) == 1 ? 1 - plane : plane;
+        if (row < S) {
+            float *dst = d_board + (size_t)tree * 2 * SIZE + out_plane * SIZE + row * S;
+#pragma unroll
+            for (int c = 0; c < S; c++) dst[c] = (float)((rb >> c) & 1u);
+        }
+    }
+}
+
+// --------------------------------------------------------- Dirichlet noise
+// Production replacement of gsl_ran_dirichlet (mcts/src/node.cpp:38): row r of
+// the table = SIZE independent Gamma(alpha, 1) draws divided by their sum.
+// Counter-based generator: draw j of (seed, row, action) is a hash of those
+// four numbers, so rows can be produced in any order and on any device.
+// Gamma: Marsaglia-Tsang squeeze with the alpha < 1 boost G(a) = G(a+1) U^(1/a);
+// normals by Box-Muller.  Not GSL's stream: validated statistically.
+__device__ __forceinline__ double u01(unsigned long long seed, unsigned row, unsigned a, unsigned j)
+{
+    const unsigned long long x = mix64(mix64(seed ^ ((unsigned long long)row << 32 | a)) + 0x9e3779b97f4a7c15ull * ((unsigned long long)j + 1ull));
+    return ((double)(x >> 11) + 0.5) * (1.0 / 9007199254740992.0); // in (0, 1)
+}
+__device__ double gamma_draw(double alpha, unsigned long long seed, unsigned row, unsigned a)
+{
+    const double a1 = alpha < 1. ? alpha + 1. : alpha;
+    const double d = a1 - 1. / 3.;
+    const double c = 1. / sqrt(9. * d);
+    unsigned j = 0;
+    double g = d; // value after 64 rejected rounds (probability below 1e-80): the mode-like d
+    for (int it = 0; it < 64; it++) {
+        const double u1 = u01(seed, row, a, j), u2 = u01(seed, row, a, j + 1), u3 = u01(seed, row, a, j + 2);
+        j += 3;
+        const double x = sqrt(-2. * log(u1)) * cos(6.283185307179586 * u2);
+        double v = 1. + c * x;
+        if (v <= 0.) continue;
+        v = v * v * v;
+        if (log(u3) < 0.5 * x * x + d - d * v + d * log(v)) { g = d * v; break; }
+    }
+    if (alpha < 1.) g *= pow(u01(seed, row, a, 0xFFFFFFFFu), 1. / alpha);
+    return g;
+}
+__global__ __launch_bounds__(64) void k_dirichlet(double *table, int rows, double alpha, unsigned long long seed)
+{
+    constexpr int E = EPL;
+    const int row = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (row >= rows) return;
+    double g[E];
+    double part = 0.;
+#pragma unroll
+    for (int k = 0; k < E; k++) {
+        const int a = lane * E + k;
+        g[k] = a < SIZE ? gamma_draw(alpha, seed, (unsigned)row, (unsigned)a) : 0.;
+        part += g[k];
+    }
+    // butterfly: every lane ends with the same total (fixed association)
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) part += __shfl_xor(part, o);
+    double out[E];
+#pragma unroll
+    for (int k = 0; k < E; k++) out[k] = g[k] / part;
+    st_f64<E>(reinterpret_cast<char *>(table + (size_t)row * SP), lane, out);
+}
+
 int launch_status()
 {
     return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
@@ -1372,6 +1523,18 @@ int l_get_counts(const AzParams &P, int *d_counts, int *d_root_n, void *stream)
     hipLaunchKernelGGL(k_get_counts, dim3(P.n_trees), dim3(64), 0, (hipStream_t)stream, P, d_counts, d_root_n);
     return launch_status();
 }
+int l_choose_moves(const AzParams &P, const double *d_u, int greedy, int *d_actions, float *d_pi, float *d_board,
+                   void *stream)
+{
+    hipLaunchKernelGGL(k_choose_moves, dim3(P.n_trees), dim3(64), 0, (hipStream_t)stream, P, d_u, greedy, d_actions,
+                       d_pi, d_board);
+    return launch_status();
+}
+int l_dirichlet(double *d_table, int rows, double alpha, unsigned long long seed, void *stream)
+{
+    hipLaunchKernelGGL(k_dirichlet, dim3(rows), dim3(64), 0, (hipStream_t)stream, d_table, rows, alpha, seed);
+    return launch_status();
+}
 
 } // namespace
 
@@ -1384,6 +1547,7 @@ extern "C" const AzShapeOps *AZ_CAT(az_shape_ops_, AZ_S)(void)
 {
     static const AzShapeOps ops = {
         AZ_S, SP, l_simulate_fused, l_select, l_expand_backup, l_make_move, l_clear, l_select_greedy, l_get_counts,
+        l_choose_moves, l_dirichlet,
     };
     return &ops;
 }

@@ -57,6 +57,13 @@ SYMBOLS = [
     ("az_make_movexy", _i, [_vp, _i, _i, _i]),
     ("az_select_greedy", _i, [_vp, _vp, _vp]),
     ("az_get_counts", _i, [_vp, _vp, _vp]),
+    ("az_choose_moves", _i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    ("az_fill_noise_dirichlet", _i, [_vp, _i, C.c_ulonglong, _vp]),
+    ("az_get_noise_table", _i, [_vp, _vp, _i]),
+    ("az_aug_key_words", _i, [_i]),
+    ("az_aug_rotations", _i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("az_aug_pack_keys", _i, [_i, _i, _vp, _vp, _vp, _vp]),
+    ("az_aug_unique_average", _i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("az_get_prob", _i, [_vp, _i, _vp]),
     ("az_get_board", _i, [_vp, _i, _vp]),
     ("az_get_raw_board", _i, [_vp, _i, _vp]),
@@ -237,6 +244,20 @@ class Engine:
     def sync_check(self, stream=None): self._check(self.L.az_sync_check(self.h, stream))
 
     # ---- results
+    def choose_moves(self, d_u, greedy, d_actions, d_pi=None, d_board=None, stream=None):
+        """Move decision + training record fields on the GPU (device pointers)."""
+        self._check(self.L.az_choose_moves(self.h, _ptr(d_u) if d_u is not None else None, int(bool(greedy)),
+                                           _ptr(d_actions), _ptr(d_pi) if d_pi is not None else None,
+                                           _ptr(d_board) if d_board is not None else None, stream))
+
+    def fill_noise_dirichlet(self, rows, seed, stream=None):
+        self._check(self.L.az_fill_noise_dirichlet(self.h, int(rows), int(seed) & 0xFFFFFFFFFFFFFFFF, stream))
+
+    def get_noise_table(self, rows):
+        out = np.zeros((rows, self.size), np.float64)
+        self._check(self.L.az_get_noise_table(self.h, _ptr(out), rows))
+        return out
+
     def get_counts(self):
         counts = np.empty((self.n_trees, self.size), np.int32)
         root_n = np.empty(self.n_trees, np.int32)

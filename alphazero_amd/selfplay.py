@@ -54,8 +54,7 @@ class TreeBatch:
         if self.eng.get_eps() == 0.0 or rows <= self._noise_rows:
             return
         rows = max(rows, 1024)
-        rng = np.random.default_rng(self.noise_seed)
-        self.eng.set_noise_table(rng.dirichlet(np.full(self.size, self.eng.get_alpha()), size=rows))
+        self.eng.fill_noise_dirichlet(rows, self.noise_seed)  # on the GPU, replaces gsl_ran_dirichlet (node.cpp:38)
         self._noise_rows = rows
 
     def set_noise_table(self, table):
@@ -124,17 +123,30 @@ class TreeBatch:
         return self.eng.get_states()[2]
 
 
+def choice_from_uniform(pi, u):
+    """numpy.random.choice(len(pi), p=pi) (src/self_play.py:164) for a given
+    uniform number u in [0,1): cdf = cumsum(p) in fp64, cdf /= cdf[-1],
+    searchsorted(cdf, u, side='right').  The random stream is the one input the
+    GPU path cannot share with numpy, so it is made explicit; numpy's check
+    that p sums to 1 within sqrt(eps) is not replicated (pi is renormalised by
+    the division, a float32 pi that misses the tolerance does not abort the game)."""
+    cdf = np.cumsum(np.asarray(pi, np.float64))
+    cdf /= cdf[-1]
+    return int(min(np.searchsorted(cdf, u, side="right"), len(cdf) - 1))
+
+
 def _choose_moves(pi, greedy, rng):
-    """src/self_play.py:159-164: argmax + one-hot pi when greedy, else sample from pi."""
+    """src/self_play.py:159-164: argmax + one-hot pi when greedy, else sample from pi
+    (one uniform number per game, drawn in game order)."""
     moves = np.empty(pi.shape[0], np.int64)
+    u = None if greedy else rng.random(pi.shape[0])
     for j in range(pi.shape[0]):
         if greedy:
             m = int(pi[j].argmax())
             pi[j, :] = 0
             pi[j, m] = 1
         else:
-            p = pi[j].astype(np.float64)
-            m = int(rng.choice(pi.shape[1], p=p / p.sum()))
+            m = choice_from_uniform(pi[j], u[j])
         moves[j] = m
     return moves
 
@@ -185,6 +197,89 @@ def self_play_games(batch0, batch1, sims, tau, init_moves=(), rng=None):
         else:
             rec["r"] = 1e-3  # draw (or the move limit was reached)
         out.append(rec)
+    return out
+
+
+def self_play_games_device(batch0, batch1, sims, tau, init_moves=(), rng=None):
+    """self_play_games with the per-move work kept on the GPU: visit-count
+    distribution, move choice, the record's board and pi (az_choose_moves) and
+    the move itself never visit the host; per half-move the host uploads one
+    uniform number per game (while sampling) and reads the winners.  The record
+    slabs come back once, at the end.  Same results as self_play_games for the
+    same `rng` (it is consumed identically: one number per live game, in game
+    order, only while i <= tau)."""
+    torch = batch0.torch
+    rng = np.random.default_rng() if rng is None else rng
+    G, S, size = batch0.n_trees, batch0.shape, batch0.size
+    assert batch1.n_trees == G and batch1.shape == S
+    dev = batch0.dev
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for m in init_moves:
+        batch0.make_move(np.full(G, m, np.int32))
+        batch1.make_move(np.full(G, m, np.int32))
+    d_act = torch.empty(G, dtype=torch.int32, device=dev)
+    d_u = torch.zeros(G, dtype=torch.float64, device=dev)
+    slabs = ([], [])          # per side: list of (pi [G,SIZE], board [G,2,S,S]) device tensors, one per ply
+    played = ([], [])         # per side: list of bool[G] = game was alive at that ply
+    alive = np.ones(G, bool)
+    for i in range(size):
+        for side, searcher in ((0, batch0), (1, batch1)):
+            if not alive.any():
+                break
+            searcher.simulate(sims, alive)  # leaves exactly the live trees active
+            greedy = i > tau
+            if not greedy:
+                u = np.zeros(G)
+                u[alive] = rng.random(int(alive.sum()))
+                d_u.copy_(torch.from_numpy(u))
+            pi = torch.empty((G, size), dtype=torch.float32, device=dev)
+            board = torch.empty((G, 2, S, S), dtype=torch.float32, device=dev)
+            searcher.eng.choose_moves(None if greedy else d_u.data_ptr(), greedy, d_act.data_ptr(), pi.data_ptr(),
+                                      board.data_ptr(), stream)
+            slabs[side].append((pi, board))
+            played[side].append(alive.copy())
+            try:
+                batch0.eng.make_move_device(d_act.data_ptr(), stream)
+                batch1.eng.make_move_device(d_act.data_ptr(), stream)
+                searcher.eng.sync_check(stream)
+                (batch1 if searcher is batch0 else batch0).eng.sync_check(stream)
+            except _E.EngineError as e:
+                raise RuntimeError(str(e)) from None
+            alive &= batch0.winners() == -1.0
+        if not alive.any():
+            break
+    winner = batch0.winners()
+    dt = sample_dtype(S)
+    host = []
+    for side in (0, 1):
+        if slabs[side]:
+            pis = torch.stack([p for p, _ in slabs[side]]).cpu().numpy()      # [plies, G, SIZE]
+            boards = torch.stack([b for _, b in slabs[side]]).cpu().numpy()   # [plies, G, 2, S, S]
+            mask = np.stack(played[side])                                      # [plies, G]
+        else:
+            pis = np.zeros((0, G, size), np.float32)
+            boards = np.zeros((0, G, 2, S, S), np.float32)
+            mask = np.zeros((0, G), bool)
+        host.append((pis, boards, mask))
+    out = []
+    for g in range(G):
+        parts = []
+        for side in (0, 1):
+            pis, boards, mask = host[side]
+            sel = mask[:, g]
+            rec = np.zeros(int(sel.sum()), dt)
+            rec["board"] = boards[sel, g]
+            rec["pi"] = pis[sel, g]
+            rec["r"] = -1.0
+            parts.append(rec)
+        if winner[g] == 0.0:
+            parts[0]["r"] = 1.0
+        elif winner[g] == 1.0:
+            parts[1]["r"] = 1.0
+        else:
+            parts[0]["r"] = 1e-3
+            parts[1]["r"] = 1e-3
+        out.append(np.concatenate(parts))
     return out
 
 

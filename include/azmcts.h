@@ -111,6 +111,17 @@ int az_set_active(az_engine *e, const unsigned char *mask);
  * (cmcts.cpp:132-133), so every call replays the same stream.  rows = 0 removes
  * the table (then eps must be 0).  Replaces gsl_ran_dirichlet at node.cpp:38. */
 int az_set_noise_table(az_engine *e, const double *noise, int rows);
+/* Production replacement of the gsl_ran_dirichlet call of Node::set_prior
+ * (mcts/src/node.cpp:38): fills the engine's noise table on the GPU with `rows`
+ * rows of Dirichlet(alpha, ..., alpha) over the SIZE actions (alpha = the
+ * engine's, cmcts.cpp:56-81), from a counter-based generator keyed by `seed`
+ * (Marsaglia-Tsang gamma draws normalised by their sum).  Same seed, same
+ * table; it is not GSL's stream.  Row k feeds the k-th expansion of a simulate
+ * call, like a table given to az_set_noise_table. */
+int az_fill_noise_dirichlet(az_engine *e, int rows, unsigned long long seed, void *stream);
+/* copies the first `rows` rows of the current noise table to host memory
+ * [rows][SIZE] (tests and diagnostics) */
+int az_get_noise_table(az_engine *e, double *noise, int rows);
 
 /* Cmcts::simulate (cmcts.cpp:83-125) with the evaluator computed in-kernel:
  * n searches on every active tree, whole call in one launch.  Thread fan-out
@@ -147,6 +158,24 @@ int az_make_movexy(az_engine *e, int tree, int x, int y);
  * `pi.argmax()` picks at src/eval.py:192, src/self_play.py:160); -1 for
  * inactive trees.  Result stays on the device for az_make_move(on_device=1). */
 int az_select_greedy(az_engine *e, int *d_actions, void *stream);
+
+/* One move decision of self_play_game / eval_game for every active tree, on the
+ * GPU (src/self_play.py:157-165,172-181; src/eval.py:191-193,201-203):
+ *   pi   = Cmcts::get_prob (mcts/src/cmcts.cpp:317-341), incl. its "Not a
+ *          distribution" check (reported by az_sync_check with the tree index);
+ *   move = greedy ? pi.argmax() (first maximum), pi := one-hot
+ *                 : numpy.random.choice(SIZE, p=pi) evaluated for the uniform
+ *                   number d_u[tree] in [0,1): cdf = cumsum(p) in fp64 and index
+ *                   order, cdf /= cdf[-1], move = #{cdf <= u};
+ *   board= State::get_board (mcts/src/state.cpp:39-48), plane 0 = side to move,
+ *          taken before the move like the callers do.
+ * d_actions [n_trees] receives the move (-1 for inactive trees), d_pi
+ * [n_trees][SIZE] and d_board [n_trees][2][S][S] (either may be NULL) receive the
+ * training record fields; rows of inactive trees are left untouched.  d_u may
+ * be NULL when greedy.  The moves are NOT applied: pass d_actions to
+ * az_make_move(..., actions_on_device = 1, ...). */
+int az_choose_moves(az_engine *e, const double *d_u, int greedy, int *d_actions, float *d_pi, float *d_board,
+                    void *stream);
 
 /* root statistics of every tree: counts int32 [n_trees][SIZE] (Node::counts,
  * node.cpp:160-164), root_n int32 [n_trees] (Node::nodeN; -1 = unexpanded).
@@ -190,6 +219,29 @@ int az_sync_check(az_engine *e, void *stream);
  * returns elapsed milliseconds. */
 int az_timing_begin(az_engine *e, void *stream);
 int az_timing_end(az_engine *e, void *stream, float *ms);
+
+/* ---- trainer-side sample preparation (src/tools.py:46-88), no engine needed.
+ * Samples are the record fields of src/self_play.py:153 as dense device arrays:
+ * board float32 [n][2][S][S], pi float32 [n][S*S], r float32 [n]. */
+
+/* get_rotations (src/tools.py:67-88): writes, for every record i in order, its 7
+ * derived symmetries as records i*7 + 0..6 (three np.rot90 turns, the row flip
+ * of the third, three turns of that); the caller keeps the originals in front,
+ * as the reference's np.concatenate([data, rotations]) does. */
+int az_aug_rotations(int shape, int n, const float *d_board, const float *d_pi, const float *d_r, float *d_board_out,
+                     float *d_pi_out, float *d_r_out, void *stream);
+/* get_unique, step 1 (src/tools.py:49): sort keys whose unsigned word-by-word
+ * order is np.unique's lexicographic board order.  d_keys [words][n], words =
+ * az_aug_key_words(shape); *d_bad is set when a board cell is neither 0 nor 1. */
+int az_aug_key_words(int shape);
+int az_aug_pack_keys(int shape, int n, const float *d_board, unsigned long long *d_keys, int *d_bad, void *stream);
+/* get_unique, step 2 (src/tools.py:56-63): d_members = record indices sorted by
+ * (key, index); distinct board u owns d_members[d_seg_start[u] .. d_seg_start[u+1]).
+ * Output record u: the board, and pi / r averaged over its occurrences in
+ * float32 with numpy's summation orders (a single occurrence is copied). */
+int az_aug_unique_average(int shape, int n_unique, const int *d_members, const int *d_seg_start, const float *d_board,
+                          const float *d_pi, const float *d_r, float *d_board_out, float *d_pi_out, float *d_r_out,
+                          void *stream);
 
 #ifdef __cplusplus
 }

@@ -59,8 +59,10 @@ def oracle_self_play_game(t0, t1, sims, tau, ev, rng, noise=None):
                 pi[:] = 0
                 pi[move] = 1
             else:
-                p = pi.astype(np.float64)
-                move = int(rng.choice(pi.size, p=p / p.sum()))
+                # numpy.random.choice(p=pi) for the stream's next uniform number
+                cdf = np.cumsum(pi.astype(np.float64))
+                cdf /= cdf[-1]
+                move = int(np.searchsorted(cdf, rng.random(), side="right"))
             mine.append([board, pi.copy(), -1.0])
             t0.make_move(move)
             t1.make_move(move)

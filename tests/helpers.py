@@ -92,3 +92,23 @@ def oracle_eval_game(t_first, sims_first, ev_first, t_second, sims_second, ev_se
             t_second.make_move(move)
             if t_first.winner != -1:
                 return
+
+
+class LegacyStream:
+    """The uniform numbers numpy's legacy global generator hands to
+    np.random.choice after np.random.seed(seed) (one per sampled move), behind
+    the `.random()` name the drivers call."""
+
+    def __init__(self, seed):
+        self.rs = np.random.RandomState(seed)
+
+    def random(self, n=None):
+        return self.rs.random_sample(n)
+
+
+def replay_board(shape, moves):
+    """raw planes [2,S,S] after the alternating move list (first mover on plane 0)."""
+    b = np.zeros((2, shape * shape), np.float32)
+    for k, m in enumerate(moves):
+        b[k % 2, m] = 1
+    return b.reshape(2, shape, shape)

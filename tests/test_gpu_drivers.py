@@ -182,3 +182,59 @@ def test_cmcts_facade_runs_reference_shaped_game(tmp_path):
         m.get_prob()
     assert "Move count: 0" in repr(m)
     m.clear()
+
+
+# ---- games played by the reference's own caller functions (tests/golden/caller_games.npz)
+import os as _os
+
+_CALLER = np.load(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "caller_games.npz"))
+
+
+@pytest.mark.parametrize("name", ["sp0", "sp1", "sp2"])
+@pytest.mark.parametrize("driver", ["host", "device"])
+def test_drivers_reproduce_reference_self_play_game(name, driver):
+    from alphazero_amd import selfplay as sp
+    from helpers import LegacyStream
+
+    S = int(_CALLER["shape"])
+    sims, tau, seed = (int(x) for x in _CALLER[f"{name}_params"])
+    eps = float(_CALLER[f"{name}_eps"])
+    ev = ExactTorchEvaluator()
+    b0 = sp.TreeBatch(1, S, ev, cpuct=4.0, eps=eps, nodes_per_tree=sims * 8)
+    b1 = sp.TreeBatch(1, S, ev, cpuct=4.0, eps=eps, nodes_per_tree=sims * 8)
+    if f"{name}_noise" in _CALLER:
+        b0.set_noise_table(_CALLER[f"{name}_noise"])
+        b1.set_noise_table(_CALLER[f"{name}_noise"])
+    play = sp.self_play_games if driver == "host" else sp.self_play_games_device
+    games = play(b0, b1, sims, tau, init_moves=[int(m) for m in _CALLER[f"{name}_opening"]], rng=LegacyStream(seed))
+    want = _CALLER[f"{name}_data"]
+    got = games[0]
+    assert got.dtype == want.dtype and len(got) == len(want)
+    assert np.array_equal(got["board"], want["board"])
+    assert np.array_equal(got["pi"].view(np.uint32), want["pi"].view(np.uint32))
+    assert np.array_equal(got["r"], want["r"])
+    assert float(b0.winners()[0]) == float(_CALLER[f"{name}_winner"])
+    b0.close()
+    b1.close()
+
+
+@pytest.mark.parametrize("name", ["ev0", "ev1"])
+def test_eval_games_reproduce_reference_eval_game(name):
+    from alphazero_amd import selfplay as sp
+    from helpers import replay_board
+
+    S = int(_CALLER["shape"])
+    s_first, s_second = (int(x) for x in _CALLER[f"{name}_params"])
+    opening = [int(m) for m in _CALLER[f"{name}_opening"]]
+    ev = ExactTorchEvaluator()
+    best = sp.TreeBatch(1, S, ev, cpuct=4.0, eps=0.0, nodes_per_tree=64 * 8)
+    latest = sp.TreeBatch(1, S, ev, cpuct=4.0, eps=0.0, nodes_per_tree=64 * 8)
+    tallies = sp.eval_games(best, latest, s_first, s_second, init_moves=opening)  # game 0: `best` opens
+    winner = float(_CALLER[f"{name}_winner"])
+    assert float(best.winners()[0]) == winner
+    first_player = len(opening) % 2
+    assert tallies == ((1, 0, 0) if winner == first_player else (0, 1, 0) if winner == 1 - first_player else (0, 0, 1))
+    assert np.array_equal(best.eng.get_raw_boards()[0].astype(np.float32),
+                          replay_board(S, opening + [int(m) for m in _CALLER[f"{name}_moves"]]))
+    best.close()
+    latest.close()

@@ -467,6 +467,18 @@ int az_sync_check(az_engine *e, void *stream)
     return sync_check_impl(e, stream, nullptr);
 }
 
+int az_sync_states(az_engine *e, void *stream, int *player, int *move_cnt, float *winner)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    if (int rc = sync_check_impl(e, stream, nullptr)) return rc;
+    for (int t = 0; t < e->n_trees; t++) { // from the headers the check has just fetched
+        if (player) player[t] = e->h_trees[t].player;
+        if (move_cnt) move_cnt[t] = e->h_trees[t].move_cnt;
+        if (winner) winner[t] = e->h_trees[t].winner;
+    }
+    return AZ_OK;
+}
+
 int az_make_move(az_engine *e, const int *actions, int on_device, void *stream)
 {
     if (!e || !actions) return fail(AZ_ERR_ARG, "null argument");

@@ -176,6 +176,13 @@ __device__ __forceinline__ unsigned long long wave_argmax_f64(double v, bool ok,
     return __ballot(ok && khi == mhi && klo == mlo);
 }
 
+// node arena of one tree (wave-uniform) and a record's byte offset inside it
+// (az_create keeps cap * REC_BYTES below 4 GiB)
+__device__ __forceinline__ char *arena_ptr(const AzParams &P, int tree)
+{
+    return P.nodes + (size_t)tree * P.cap * REC_BYTES;
+}
+__device__ __forceinline__ unsigned rec_off(int slot) { return (unsigned)slot * (unsigned)REC_BYTES; }
 __device__ __forceinline__ char *rec_ptr(const AzParams &P, int tree, int slot)
 {
     // 64-bit arena base (loop-invariant) + 32-bit offset inside the tree's arena
@@ -184,9 +191,11 @@ __device__ __forceinline__ char *rec_ptr(const AzParams &P, int tree, int slot)
 }
 
 // thread-blocked vector loads / stores of one per-action array of a record
-template <int E> __device__ __forceinline__ void ld_i32(const char *base, unsigned tid, int (&out)[E])
+// (base + one zero-extended 32-bit byte offset: with a wave-uniform base this
+// selects the scalar-base + vector-offset addressing form, one VALU add per access)
+template <int E> __device__ __forceinline__ void ld_i32(const char *base, unsigned off, unsigned tid, int (&out)[E])
 {
-    const int *p = reinterpret_cast<const int *>(base) + tid * E;
+    const int *p = reinterpret_cast<const int *>(base + (off + tid * (unsigned)(E * 4)));
     if constexpr (E % 4 == 0) {
 #pragma unroll
         for (int j = 0; j < E / 4; j++) {
@@ -204,9 +213,9 @@ template <int E> __device__ __forceinline__ void ld_i32(const char *base, unsign
         for (int j = 0; j < E; j++) out[j] = p[j];
     }
 }
-template <int E> __device__ __forceinline__ void st_i32(char *base, unsigned tid, const int (&in)[E])
+template <int E> __device__ __forceinline__ void st_i32(char *base, unsigned off, unsigned tid, const int (&in)[E])
 {
-    int *p = reinterpret_cast<int *>(base) + tid * E;
+    int *p = reinterpret_cast<int *>(base + (off + tid * (unsigned)(E * 4)));
     if constexpr (E % 4 == 0) {
 #pragma unroll
         for (int j = 0; j < E / 4; j++)
@@ -220,9 +229,9 @@ template <int E> __device__ __forceinline__ void st_i32(char *base, unsigned tid
         for (int j = 0; j < E; j++) p[j] = in[j];
     }
 }
-template <int E> __device__ __forceinline__ void ld_f64(const char *base, unsigned tid, double (&out)[E])
+template <int E> __device__ __forceinline__ void ld_f64(const char *base, unsigned off, unsigned tid, double (&out)[E])
 {
-    const double *p = reinterpret_cast<const double *>(base) + tid * E;
+    const double *p = reinterpret_cast<const double *>(base + (off + tid * (unsigned)(E * 8)));
     if constexpr (E % 2 == 0) {
 #pragma unroll
         for (int j = 0; j < E / 2; j++) {
@@ -234,9 +243,9 @@ template <int E> __device__ __forceinline__ void ld_f64(const char *base, unsign
         for (int j = 0; j < E; j++) out[j] = p[j];
     }
 }
-template <int E> __device__ __forceinline__ void st_f64(char *base, unsigned tid, const double (&in)[E])
+template <int E> __device__ __forceinline__ void st_f64(char *base, unsigned off, unsigned tid, const double (&in)[E])
 {
-    double *p = reinterpret_cast<double *>(base) + tid * E;
+    double *p = reinterpret_cast<double *>(base + (off + tid * (unsigned)(E * 8)));
     if constexpr (E % 2 == 0) {
 #pragma unroll
         for (int j = 0; j < E / 2; j++)
@@ -251,24 +260,26 @@ template <int E> __device__ __forceinline__ void st_f64(char *base, unsigned tid
 template <int E>
 __device__ __forceinline__ void load_node(const AzParams &P, int tree, int slot, int tid, bool fresh, NodeRegs<E> &nd)
 {
-    const char *rec = rec_ptr(P, tree, slot);
-    ld_f64<E>(rec + OFF_P, tid, nd.p);
+    const char *arena = arena_ptr(P, tree);
+    const unsigned ro = rec_off(slot);
+    ld_f64<E>(arena, ro + OFF_P, tid, nd.p);
     if (fresh) {
 #pragma unroll
         for (int k = 0; k < E; k++) { nd.n[k] = 0; nd.link[k] = 0; nd.w[k] = 0.; }
     } else {
-        ld_i32<E>(rec + OFF_N, tid, nd.n);
-        ld_i32<E>(rec + OFF_LINK, tid, nd.link);
-        ld_f64<E>(rec + OFF_W, tid, nd.w);
+        ld_i32<E>(arena, ro + OFF_N, tid, nd.n);
+        ld_i32<E>(arena, ro + OFF_LINK, tid, nd.link);
+        ld_f64<E>(arena, ro + OFF_W, tid, nd.w);
     }
 }
 template <int E>
 __device__ __forceinline__ void store_stats(const AzParams &P, int tree, int slot, int tid, const NodeRegs<E> &nd)
 {
-    char *rec = rec_ptr(P, tree, slot);
-    st_i32<E>(rec + OFF_N, tid, nd.n);
-    st_i32<E>(rec + OFF_LINK, tid, nd.link);
-    st_f64<E>(rec + OFF_W, tid, nd.w);
+    char *arena = arena_ptr(P, tree);
+    const unsigned ro = rec_off(slot);
+    st_i32<E>(arena, ro + OFF_N, tid, nd.n);
+    st_i32<E>(arena, ro + OFF_LINK, tid, nd.link);
+    st_f64<E>(arena, ro + OFF_W, tid, nd.w);
 }
 
 // ------------------------------------------------------------------- rules
@@ -636,7 +647,7 @@ __device__ __forceinline__ void mix_prior(const AzParams &P, const float (&pr)[E
 #pragma unroll
     for (int k = 0; k < E; k++) nz[k] = 0.;
     if (P.noise != nullptr) {
-        ld_f64<E>(reinterpret_cast<const char *>(P.noise + (size_t)noise_row * SP), tid, nz);
+        ld_f64<E>(reinterpret_cast<const char *>(P.noise), (unsigned)noise_row * (unsigned)(SP * 8), tid, nz);
         // complete the load inside the branch: a wait placed after the merge would
         // also run (as vmcnt(0), i.e. behind every earlier store) when there is no noise
         __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -794,7 +805,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             (void)evaluate<E, EVAL>(A, s, tid, pr);
             mix_prior<E, MIX>(P, pr, false, noise_row, tid, R.p);
             if (MIX != 0 && P.noise != nullptr) noise_row++;
-            st_f64<E>(rec_ptr(P, tree, slot) + OFF_P, tid, R.p);
+            st_f64<E>(arena_ptr(P, tree), rec_off(slot) + OFF_P, tid, R.p);
 #pragma unroll
             for (int k = 0; k < E; k++) {
                 R.n[k] = 0; R.link[k] = 0; R.w[k] = 0.;
@@ -884,7 +895,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
                         }
                         store_stats<E>(P, tree, cur, tid, z);
                     } else if (tid == pk.a / E) {
-                        reinterpret_cast<int *>(rec_ptr(P, tree, cur) + OFF_N)[pk.a] = pk.n + 1;
+                        *reinterpret_cast<int *>(arena_ptr(P, tree) + (rec_off(cur) + OFF_N + (unsigned)pk.a * 4u)) = pk.n + 1;
                     }
                     if (AZ_UNLIKELY(depth >= 64)) {
                         s_node[depth - 64] = cur; s_act[depth - 64] = pk.a; s_w1[depth - 64] = pk.w - 1.;
@@ -919,14 +930,15 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             double pp[E];
             mix_prior<E, MIX>(P, pr, false, noise_row, tid, pp);
             if (MIX != 0 && P.noise != nullptr) noise_row++;
-            st_f64<E>(rec_ptr(P, tree, slot) + OFF_P, tid, pp); // statistics stay implicit zeros
+            st_f64<E>(arena_ptr(P, tree), rec_off(slot) + OFF_P, tid, pp); // statistics stay implicit zeros
             if (tid == parent_a / E) {
                 if (depth == 0) {
 #pragma unroll
                     for (int k = 0; k < E; k++)
                         if (k == parent_a % E) R.link[k] = slot + 1;
                 } else {
-                    reinterpret_cast<int *>(rec_ptr(P, tree, parent_slot) + OFF_LINK)[parent_a] = slot + 1;
+                    *reinterpret_cast<int *>(arena_ptr(P, tree) + (rec_off(parent_slot) + OFF_LINK + (unsigned)parent_a * 4u)) =
+                        slot + 1;
                 }
             }
             value = -v; // cmcts.cpp:228
@@ -942,7 +954,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
         for (; __builtin_expect(d >= 64, 0); --d) { // entries spilled to LDS (rare)
             const int act = s_act[d - 64];
             if (tid == act / E)
-                reinterpret_cast<double *>(rec_ptr(P, tree, s_node[d - 64]) + OFF_W)[act] =
+                *reinterpret_cast<double *>(arena_ptr(P, tree) + (rec_off(s_node[d - 64]) + OFF_W + (unsigned)act * 8u)) =
                     s_w1[d - 64] + ((double)value + 1.);
             value = -value;
         }
@@ -951,7 +963,8 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             double w1;
             path_get(path, d, node, act, w1);
             if (tid == act / E)
-                reinterpret_cast<double *>(rec_ptr(P, tree, node) + OFF_W)[act] = w1 + ((double)value + 1.);
+                *reinterpret_cast<double *>(arena_ptr(P, tree) + (rec_off(node) + OFF_W + (unsigned)act * 8u)) =
+                    w1 + ((double)value + 1.);
             value = -value;
         }
         if (root_owner) { // the two divisions of this search: W/N and 1/(N+1)
@@ -1089,7 +1102,7 @@ __global__ __launch_bounds__(64) void k_expand_backup(AzParams P, const float *d
         }
         NodeRegs<E> nd;
         mix_prior<E>(P, pr, prior_is_log != 0, noise_row, lane, nd.p);
-        st_f64<E>(rec_ptr(P, tree, slot) + OFF_P, lane, nd.p);
+        st_f64<E>(rec_ptr(P, tree, slot), OFF_P, lane, nd.p);
         const int parent_slot = depth > 0 ? uni(pn[depth - 1]) : -1;
         if (depth == 0) { // the new node is the root: materialise it
 #pragma unroll
@@ -1267,7 +1280,7 @@ __global__ __launch_bounds__(64) void k_select_greedy(AzParams P, int *d_actions
         return;
     }
     int n[E];
-    ld_i32<E>(rec_ptr(P, tree, root) + OFF_N, lane, n);
+    ld_i32<E>(rec_ptr(P, tree, root), OFF_N, lane, n);
     int best = -1, bk = 0;
 #pragma unroll
     for (int k = 0; k < E; k++)
@@ -1290,7 +1303,7 @@ __global__ __launch_bounds__(64) void k_get_counts(AzParams P, int *d_counts, in
     int n[E];
 #pragma unroll
     for (int k = 0; k < E; k++) n[k] = 0;
-    if (root >= 0) ld_i32<E>(rec_ptr(P, tree, root) + OFF_N, lane, n);
+    if (root >= 0) ld_i32<E>(rec_ptr(P, tree, root), OFF_N, lane, n);
     if (d_counts != nullptr) {
 #pragma unroll
         for (int k = 0; k < E; k++) {
@@ -1333,7 +1346,7 @@ __global__ __launch_bounds__(64) void k_choose_moves(AzParams P, const double *d
     int n[E];
 #pragma unroll
     for (int k = 0; k < E; k++) n[k] = 0;
-    if (root >= 0) ld_i32<E>(rec_ptr(P, tree, root) + OFF_N, lane, n);
+    if (root >= 0) ld_i32<E>(rec_ptr(P, tree, root), OFF_N, lane, n);
     float pi[E];
 #pragma unroll
     for (int k = 0; k < E; k++) {
@@ -1449,7 +1462,7 @@ __global__ __launch_bounds__(64) void k_dirichlet(double *table, int rows, doubl
     double out[E];
 #pragma unroll
     for (int k = 0; k < E; k++) out[k] = g[k] / part;
-    st_f64<E>(reinterpret_cast<char *>(table + (size_t)row * SP), lane, out);
+    st_f64<E>(reinterpret_cast<char *>(table + (size_t)row * SP), 0u, lane, out);
 }
 
 int launch_status()

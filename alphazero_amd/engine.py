@@ -73,6 +73,7 @@ SYMBOLS = [
     ("az_reset_stats", _i, [_vp]),
     ("az_get_pool_usage", _i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
     ("az_sync_check", _i, [_vp, _vp]),
+    ("az_sync_states", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("az_timing_begin", _i, [_vp, _vp]),
     ("az_timing_end", _i, [_vp, _vp, C.POINTER(_f)]),
 ]
@@ -242,6 +243,14 @@ class Engine:
         self._check(self.L.az_select_greedy(self.h, _ptr(d_actions), stream))
 
     def sync_check(self, stream=None): self._check(self.L.az_sync_check(self.h, stream))
+
+    def sync_states(self, stream=None):
+        """sync_check + get_states with one copy of the tree headers."""
+        player = np.zeros(self.n_trees, np.int32)
+        move_cnt = np.zeros(self.n_trees, np.int32)
+        winner = np.zeros(self.n_trees, np.float32)
+        self._check(self.L.az_sync_states(self.h, stream, _ptr(player), _ptr(move_cnt), _ptr(winner)))
+        return player, move_cnt, winner
 
     # ---- results
     def choose_moves(self, d_u, greedy, d_actions, d_pi=None, d_board=None, stream=None):

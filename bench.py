@@ -125,8 +125,7 @@ def main():
             kernel_ms.append(eng.timing_end(stream))
         eng.select_greedy(d_actions.data_ptr(), stream)
         eng.make_move_device(d_actions.data_ptr(), stream)
-        eng.sync_check(stream)
-        _, _, winner = eng.get_states()
+        _, _, winner = eng.sync_states(stream)
         fin = winner != -1.0
         if fin.any():
             eng.clear_masked(fin.astype(np.uint8))

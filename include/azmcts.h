@@ -213,6 +213,10 @@ int az_get_pool_usage(az_engine *e, int tree, int *used, int *max_used);
  * per-tree error raised inside a kernel (AZ_ERR_POOL_FULL, AZ_ERR_NO_ACTION,
  * AZ_ERR_NOISE_ROWS, AZ_ERR_INVALID_MOVE), clearing it. */
 int az_sync_check(az_engine *e, void *stream);
+/* az_sync_check followed by az_get_states from one device-to-host copy: what a
+ * caller does after every move (`mcts.winner != -1`, src/self_play.py:169,185;
+ * src/eval.py:194,204).  Any of the three output arrays may be NULL. */
+int az_sync_states(az_engine *e, void *stream, int *player, int *move_cnt, float *winner);
 
 /* HIP-event timing of the engine's own kernels on the stream they were
  * launched on: az_timing_begin records, az_timing_end records + waits and

@@ -576,11 +576,26 @@ __device__ __forceinline__ Pick finish_pick(const Cand &c, int tid, Slot *slots,
 
 // Node::select (mcts/src/node.cpp:85-124) on a node loaded from the pool
 template <int WPT, int E>
-__device__ __forceinline__ Pick select_pick(const NodeRegs<E> &nd, double sq, unsigned occ, double cpuct, int tid,
-                                            Slot *slots, int &phase)
+__device__ __forceinline__ Pick select_pick(const NodeRegs<E> &nd, bool fresh, double sq, unsigned occ, double cpuct,
+                                            int tid, Slot *slots, int &phase)
 {
     Cand c;
-    scan_exact<E>(nd, sq, occ, cpuct, tid, c);
+    if (fresh) {
+        // never selected from: every N and W is zero, so u = cpuct*P*sqrt(nodeN + 1e-8)
+        // (the N == 0 branch of node.cpp:107-108) and the pick hands on zeros
+        cand_init(c);
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            const int a = tid * E + k;
+            const bool valid = (a < SIZE) && !((occ >> k) & 1u);
+            const double u = (cpuct * nd.p[k]) * sq;
+            const bool gt = valid && u > c.u;
+            c.u = gt ? u : c.u;
+            c.k = gt ? k : c.k;
+        }
+    } else {
+        scan_exact<E>(nd, sq, occ, cpuct, tid, c);
+    }
     return finish_pick<WPT, E>(c, tid, slots, phase);
 }
 
@@ -877,7 +892,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
                 __builtin_amdgcn_s_waitcnt(0x0F70);
                 STAMP(2);
 #endif
-                pk = select_pick<WPT, E>(nd, sqrt_node_n(nn, s_sqrt), s.occ, P.cpuct, tid, s_slots, phase);
+                pk = select_pick<WPT, E>(nd, fresh, sqrt_node_n(nn, s_sqrt), s.occ, P.cpuct, tid, s_slots, phase);
                 STAMP(3);
                 if (AZ_UNLIKELY(pk.a < 0)) {
                     leaf = NO_ACTION;
@@ -1025,7 +1040,7 @@ __global__ __launch_bounds__(64) void k_select(AzParams P, float *d_boards, int 
         const bool fresh = nn == 0 && cur != root; // a root is always materialised
         NodeRegs<E> nd;
         load_node<E>(P, tree, cur, lane, fresh, nd);
-        const Pick pk = select_pick<1, E>(nd, sqrt_node_n(nn, nullptr), s.occ, P.cpuct, lane, nullptr, phase);
+        const Pick pk = select_pick<1, E>(nd, fresh, sqrt_node_n(nn, nullptr), s.occ, P.cpuct, lane, nullptr, phase);
         if (pk.a < 0) { err = AZ_ERR_NO_ACTION; break; }
         n_sel++;
         char *rec = rec_ptr(P, tree, cur);

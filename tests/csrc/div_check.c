@@ -40,6 +40,10 @@ int main(int argc, char **argv)
         double r = 1.0 / b;
         tested++;
         if (seq(t, b, r) != t / b) bad++;
+        /* value sums divided by visit counts: either sign, |W| <= N */
+        double w = ((double)(next() >> 11) / 9007199254740992.0 * 2.0 - 1.0) * b;
+        tested++;
+        if (seq(w, b, r) != w / b) bad++;
     }
     /* adversarial: numerators next to exact multiples and to rounding midpoints */
     for (int bi = 1; bi <= max_b; bi++) {

@@ -1,0 +1,241 @@
+// Batched policy/value network evaluation for the stepped search path: the
+// reference's `simplerNN` (src/model.py:9-44; called once per expansion with
+// batch 1 at mcts/src/cmcts.cpp:206-231) for ALL leaf positions of a search
+// step in one launch, inference mode (batch-norm folded to scale/shift).
+//
+// gfx950 design: a workgroup of four wavefronts owns one position at a time.
+// The 16-channel activations of the whole net stay in LDS (three planes-major
+// buffers with a zero halo), so HBM sees only the input planes and the outputs.
+// Every 3x3 convolution is an implicit GEMM on the f32-input matrix cores
+// (v_mfma_f32_16x16x4_f32: exact f32 products, f32 accumulate): M = 16 pixels of
+// one board row, N = the 16 output channels, K = 4 input channels of one tap;
+// each wavefront carries four independent accumulators (four rows), which is
+// what the 40-cycle dependent latency of that instruction needs.  The 1-channel
+// heads run on the VALU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/azmcts.h"
+
+namespace {
+
+constexpr int CH = 16;  // conv channels of the reference configuration (config.py:15)
+constexpr int CIN = 2;  // input planes (config.py:12)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int S> struct Geo {
+    static constexpr int SIZE = S * S;
+    static constexpr int ROW = S + 2;               // one halo column on each side
+    static constexpr int PLANE = ROW * ROW;
+    static constexpr int TPR = (S + 15) / 16;       // 16-pixel tiles per board row
+    static constexpr int NT = S * TPR;              // tiles per plane
+    // plane stride: room for the over-reads of the padded tile lanes, and = 16 mod 32
+    // so the four K-groups of a wavefront hit disjoint LDS banks
+    static constexpr int PS = ((PLANE + 16 * TPR + 31) / 32) * 32 + 16;
+};
+
+// packed parameter block (floats), built by the host:
+//   first layer : B[5][64], scale[16], shift[16]
+//   each 16->16 : B[36][64], scale[16], shift[16]      (front-1, policy, value layers in that order)
+//   policy head : w[9][16], bias
+//   value head  : w[16], bias
+constexpr int FIRST_FLOATS = 5 * 64 + 32;
+constexpr int LAYER_FLOATS = 36 * 64 + 32;
+constexpr int POLICY_FLOATS = 9 * CH + 1;
+constexpr int VALUE_FLOATS = CH + 1;
+
+// one 3x3 convolution + folded batch norm + ReLU, `in` -> `out` (LDS planes).
+// KSTEPS = 36 for 16 input channels (tap-major, 4 channels per step), 5 for the
+// 2-plane input layer (K index = tap*2 + plane, padded with zero weights).
+template <int S, int KSTEPS>
+__device__ __forceinline__ void conv3x3(const float *in, float *out, const float *prm, int wave, int lane)
+{
+    using G = Geo<S>;
+    float b[KSTEPS];
+#pragma unroll
+    for (int i = 0; i < KSTEPS; i++) b[i] = prm[i * 64 + lane];
+    const int co = lane & 15, kq = lane >> 4;
+    const float sc = prm[KSTEPS * 64 + co], sh = prm[KSTEPS * 64 + 16 + co];
+    for (int tile0 = wave * 4; tile0 < G::NT; tile0 += 16) {
+        f32x4 acc[4];
+        int base[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int tile = tile0 + t < G::NT ? tile0 + t : G::NT - 1;
+            const int y = tile / G::TPR, x = (tile % G::TPR) * 16 + (lane & 15);
+            base[t] = (y + 1) * G::ROW + x + 1;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ks++) {
+            int tap, ci;
+            if (KSTEPS == 36) { tap = ks >> 2; ci = (ks & 3) * 4 + kq; }
+            else { const int kk = ks * 4 + kq; tap = kk < 18 ? kk >> 1 : 0; ci = kk & 1; }
+            const int off = ci * G::PS + (tap / 3 - 1) * G::ROW + (tap % 3 - 1);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(in[base[t] + off], b[ks], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int tile = tile0 + t;
+            if (tile < G::NT) {
+                const int y = tile / G::TPR, x0 = (tile % G::TPR) * 16 + kq * 4;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (x0 + r < S) out[co * G::PS + (y + 1) * G::ROW + x0 + r + 1] = fmaxf(acc[t][r] * sc + sh, 0.f);
+            }
+        }
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void k_net_eval(const float *boards, int n, const float *prm, int front, int pol,
+                                                  int val, float *value_out, float *logp_out)
+{
+    using G = Geo<S>;
+    extern __shared__ float lds[];
+    float *A = lds, *B = lds + CH * G::PS, *C = lds + 2 * CH * G::PS;
+    float *red = lds + 3 * CH * G::PS; // [8] reduction scratch + logits [SIZE]
+    float *logit = red + 8;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < 3 * CH * G::PS; i += 256) lds[i] = 0.f; // halos stay zero from here on
+    __syncthreads();
+    const float *p_layers = prm + FIRST_FLOATS;
+    const float *p_policy = p_layers + (size_t)(front - 1 + pol + val) * LAYER_FLOATS;
+    const float *p_value = p_policy + POLICY_FLOATS;
+
+    for (int pos = blockIdx.x; pos < n; pos += gridDim.x) {
+        // raw planes into channels 0..1 of A
+        for (int i = tid; i < CIN * G::SIZE; i += 256) {
+            const int c = i / G::SIZE, p = i - c * G::SIZE;
+            A[c * G::PS + (p / S + 1) * G::ROW + p % S + 1] = boards[(size_t)pos * CIN * G::SIZE + i];
+        }
+        __syncthreads();
+        // trunk: A -> B -> A -> ... ; `cur` ends up holding `front`
+        float *cur = A, *nxt = B;
+        conv3x3<S, 5>(cur, nxt, prm, wave, lane);
+        __syncthreads();
+        { float *t = cur; cur = nxt; nxt = t; }
+        for (int l = 0; l < front - 1; l++) {
+            conv3x3<S, 36>(cur, nxt, p_layers + (size_t)l * LAYER_FLOATS, wave, lane);
+            __syncthreads();
+            float *t = cur; cur = nxt; nxt = t;
+        }
+        // policy branch: cur (kept) -> nxt -> C -> nxt ...
+        const float *src = cur;
+        float *d0 = nxt, *d1 = C;
+        for (int l = 0; l < pol; l++) {
+            conv3x3<S, 36>(src, d0, p_layers + (size_t)(front - 1 + l) * LAYER_FLOATS, wave, lane);
+            __syncthreads();
+            src = d0;
+            float *t = d0; d0 = d1; d1 = t;
+        }
+        // policy head: 3x3 conv to one channel + bias, log-softmax over the board
+        float lmax = -INFINITY;
+        for (int p = tid; p < G::SIZE; p += 256) {
+            const int ctr = (p / S + 1) * G::ROW + p % S + 1;
+            float acc = p_policy[9 * CH];
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) {
+                const int off = ctr + (tap / 3 - 1) * G::ROW + (tap % 3 - 1);
+#pragma unroll
+                for (int ci = 0; ci < CH; ci++) acc += p_policy[tap * CH + ci] * src[ci * G::PS + off];
+            }
+            logit[p] = acc;
+            lmax = fmaxf(lmax, acc);
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+        if (lane == 0) red[wave] = lmax;
+        __syncthreads();
+        lmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float lsum = 0.f;
+        for (int p = tid; p < G::SIZE; p += 256) lsum += expf(logit[p] - lmax);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) lsum += __shfl_xor(lsum, o);
+        if (lane == 0) red[4 + wave] = lsum;
+        __syncthreads();
+        const float lse = lmax + logf((red[4] + red[5]) + (red[6] + red[7]));
+        for (int p = tid; p < G::SIZE; p += 256) logp_out[(size_t)pos * G::SIZE + p] = logit[p] - lse;
+        __syncthreads(); // `red`, `logit` and the policy buffers are free again
+        // value branch: front (cur) -> ... ; the policy buffers are reused
+        src = cur;
+        d0 = nxt; d1 = C;
+        for (int l = 0; l < val; l++) {
+            conv3x3<S, 36>(src, d0, p_layers + (size_t)(front - 1 + pol + l) * LAYER_FLOATS, wave, lane);
+            __syncthreads();
+            src = d0;
+            float *t = d0; d0 = d1; d1 = t;
+        }
+        // value head: 1x1 conv + bias, board average, tanh
+        float vs = 0.f;
+        for (int p = tid; p < G::SIZE; p += 256) {
+            const int ctr = (p / S + 1) * G::ROW + p % S + 1;
+#pragma unroll
+            for (int ci = 0; ci < CH; ci++) vs += p_value[ci] * src[ci * G::PS + ctr];
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) vs += __shfl_xor(vs, o);
+        if (lane == 0) red[wave] = vs;
+        __syncthreads();
+        if (tid == 0) value_out[pos] = tanhf(((red[0] + red[1]) + (red[2] + red[3])) / (float)G::SIZE + p_value[CH]);
+        __syncthreads();
+        // stale activations of this position sit only in interior cells, which the
+        // next position overwrites before reading (channels 0..1 of A by the input
+        // copy; every other plane by the layer that produces it)... except channels
+        // 2..15 of A, which the 2-plane input layer never reads.
+    }
+}
+
+template <int S> int launch(const float *boards, int n, const float *prm, int front, int pol, int val, float *value_out,
+                            float *logp_out, hipStream_t st)
+{
+    using G = Geo<S>;
+    const size_t lds_bytes = (size_t)(3 * CH * G::PS + 8 + G::SIZE) * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute((const void *)k_net_eval<S>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes) != hipSuccess)
+            return AZ_ERR_HIP;
+        configured = true;
+    }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int per_cu = (int)(160 * 1024 / lds_bytes) > 0 ? (int)(160 * 1024 / lds_bytes) : 1;
+    int grid = cus * per_cu;
+    if (grid > n) grid = n;
+    hipLaunchKernelGGL(k_net_eval<S>, dim3(grid), dim3(256), lds_bytes, st, boards, n, prm, front, pol, val, value_out,
+                       logp_out);
+    return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
+}
+
+} // namespace
+
+extern "C" {
+
+int az_net_param_floats(int front_layers, int policy_layers, int value_layers)
+{
+    if (front_layers < 1 || policy_layers < 0 || value_layers < 0) return 0;
+    return FIRST_FLOATS + (front_layers - 1 + policy_layers + value_layers) * LAYER_FLOATS + POLICY_FLOATS + VALUE_FLOATS;
+}
+
+int az_net_eval(int shape, int n, const float *d_boards, const float *d_params, int front_layers, int policy_layers,
+                int value_layers, float *d_value, float *d_logp, void *stream)
+{
+    if (n < 0 || front_layers < 1 || policy_layers < 0 || value_layers < 0) return AZ_ERR_ARG;
+    if (n == 0) return AZ_OK;
+    if (!d_boards || !d_params || !d_value || !d_logp) return AZ_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (shape) {
+#define AZ_NET_CASE(s) \
+    case s: return launch<s>(d_boards, n, d_params, front_layers, policy_layers, value_layers, d_value, d_logp, st);
+        AZ_NET_CASE(5) AZ_NET_CASE(6) AZ_NET_CASE(7) AZ_NET_CASE(8) AZ_NET_CASE(9) AZ_NET_CASE(10) AZ_NET_CASE(11)
+        AZ_NET_CASE(12) AZ_NET_CASE(13) AZ_NET_CASE(14) AZ_NET_CASE(15) AZ_NET_CASE(16) AZ_NET_CASE(17)
+        AZ_NET_CASE(18) AZ_NET_CASE(19) AZ_NET_CASE(20)
+#undef AZ_NET_CASE
+    default: return AZ_ERR_ARG;
+    }
+}
+
+} // extern "C"

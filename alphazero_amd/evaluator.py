@@ -53,3 +53,84 @@ class ConstantEvaluator:
                                 torch.full((boards.shape[0], self.size), self.prior, dtype=torch.float32,
                                            device=boards.device))
         return self._cache[key]
+
+
+class FusedNetEvaluator:
+    """The reference network (src/model.py:9-44, inference mode) evaluated by the
+    engine library's own kernel (az_net_eval: f32 matrix-core convolutions with
+    the activations resident in LDS) instead of PyTorch.  Takes a module with the
+    reference's sub-module names (`front`, `policy_conv`, `policy`, `value_conv`,
+    `value`; 2 input planes, 16 conv channels) or its state_dict; PyTorch only
+    provides the tensors."""
+
+    log_priors = True
+
+    def __init__(self, module_or_state, shape, device=0, name="fused-net"):
+        from . import engine as _E
+
+        self.L = _E.load_library()
+        self.device = torch.device("cuda", device) if not isinstance(device, torch.device) else device
+        self.shape, self.name = shape, name
+        state = module_or_state.state_dict() if hasattr(module_or_state, "state_dict") else module_or_state
+        packed, self.layers = self.pack(state)
+        assert packed.numel() == self.L.az_net_param_floats(*self.layers)
+        self.params = packed.to(self.device)
+
+    @staticmethod
+    def _fold(state, prefix, i):
+        """conv weight + inference batch norm of block i of a Sequential (conv at 3i, bn at 3i+1)."""
+        w = state[f"{prefix}.{3 * i}.weight"].detach().double().cpu()
+        g, b = state[f"{prefix}.{3 * i + 1}.weight"].double().cpu(), state[f"{prefix}.{3 * i + 1}.bias"].double().cpu()
+        mean, var = state[f"{prefix}.{3 * i + 1}.running_mean"].double().cpu(), state[f"{prefix}.{3 * i + 1}.running_var"].double().cpu()
+        scale = g / torch.sqrt(var + 1e-5)  # nn.BatchNorm2d default eps
+        return w, scale, b - mean * scale
+
+    @classmethod
+    def pack(cls, state):
+        def count(prefix):
+            n = 0
+            while f"{prefix}.{3 * n}.weight" in state:
+                n += 1
+            return n
+
+        front, pol, val = count("front"), count("policy_conv"), count("value_conv")
+        lane = torch.arange(64)
+        co, kq = lane & 15, lane >> 4
+        out = []
+        w, sc, sh = cls._fold(state, "front", 0)
+        if w.shape[:2] != (16, 2):
+            raise ValueError("the fused evaluator is built for 2 input planes and 16 conv channels")
+        b = torch.zeros(5, 64, dtype=torch.float64)
+        for ks in range(5):
+            kk = ks * 4 + kq
+            ok = kk < 18
+            tap, ci = torch.where(ok, kk >> 1, 0), kk & 1
+            b[ks] = torch.where(ok, w[co, ci, tap // 3, tap % 3], torch.zeros(64, dtype=torch.float64))
+        out += [b.reshape(-1), sc, sh]
+        blocks = [("front", i) for i in range(1, front)] + [("policy_conv", i) for i in range(pol)] + \
+                 [("value_conv", i) for i in range(val)]
+        for prefix, i in blocks:
+            w, sc, sh = cls._fold(state, prefix, i)
+            if w.shape[:2] != (16, 16):
+                raise ValueError("the fused evaluator is built for 16 conv channels")
+            b = torch.zeros(36, 64, dtype=torch.float64)
+            for tap in range(9):
+                for g in range(4):
+                    b[tap * 4 + g] = w[co, 4 * g + kq, tap // 3, tap % 3]
+            out += [b.reshape(-1), sc, sh]
+        wp = state["policy.0.weight"].detach().double().cpu()  # [1,16,3,3]
+        out += [wp[0].permute(1, 2, 0).reshape(-1), state["policy.0.bias"].detach().double().cpu().reshape(-1)]
+        wv = state["value.0.weight"].detach().double().cpu()   # [1,16,1,1]
+        out += [wv.reshape(-1), state["value.0.bias"].detach().double().cpu().reshape(-1)]
+        return torch.cat(out).to(torch.float32).contiguous(), (front, pol, val)
+
+    def __call__(self, boards):
+        n, size = boards.shape[0], self.shape * self.shape
+        boards = boards.contiguous()
+        value = torch.empty(n, dtype=torch.float32, device=boards.device)
+        logp = torch.empty((n, size), dtype=torch.float32, device=boards.device)
+        rc = self.L.az_net_eval(self.shape, n, boards.data_ptr(), self.params.data_ptr(), *self.layers,
+                                value.data_ptr(), logp.data_ptr(), torch.cuda.current_stream(boards.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"az_net_eval failed (code {rc})")
+        return value, logp

@@ -247,6 +247,20 @@ int az_aug_unique_average(int shape, int n_unique, const int *d_members, const i
                           const float *d_pi, const float *d_r, float *d_board_out, float *d_pi_out, float *d_r_out,
                           void *stream);
 
+/* ---- batched network evaluation for az_select / az_expand_backup.
+ * The reference evaluates its network (`simplerNN`, src/model.py:9-44, traced in
+ * eval mode: src/self_play.py:60-63) with batch 1 at every expansion
+ * (mcts/src/cmcts.cpp:206-231); this evaluates all n leaf boards of a search
+ * step in one launch.  d_boards: float32 [n][2][S][S] raw planes (what az_select
+ * writes); outputs d_value [n] and d_logp [n][S*S] (log-softmax, so
+ * az_expand_backup takes them with prior_is_log = 1).  d_params: the network's
+ * inference parameters packed by the host (alphazero_amd/evaluator.py,
+ * FusedNetEvaluator.pack): az_net_param_floats(...) floats; 2 input planes and
+ * 16 conv channels (config.py:12-15), layer counts as given. */
+int az_net_param_floats(int front_layers, int policy_layers, int value_layers);
+int az_net_eval(int shape, int n, const float *d_boards, const float *d_params, int front_layers, int policy_layers,
+                int value_layers, float *d_value, float *d_logp, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

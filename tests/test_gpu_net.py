@@ -1,0 +1,72 @@
+"""The library's own network kernel (az_net_eval through FusedNetEvaluator)
+against PyTorch's float64 evaluation of the same module on the CPU.  Network
+outputs are a floating-point result: tolerance 2e-5 absolute on value and
+log-probabilities (f32 products and sums in a different order than any BLAS)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(shape, front, pol, val, seed):
+    import torch
+    from alphazero_amd.model import PolicyValueNet
+
+    torch.manual_seed(seed)
+    m = PolicyValueNet(shape, 2, 16, front, pol, val)
+    # non-trivial inference statistics
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.uniform_(-0.3, 0.3)
+            mod.running_var.uniform_(0.5, 1.5)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.uniform_(-0.2, 0.2)
+    return m.eval()
+
+
+def _boards(n, shape, seed):
+    rng = np.random.default_rng(seed)
+    b = np.zeros((n, 2, shape * shape), np.float32)
+    for k in range(n):
+        stones = rng.choice(shape * shape, size=rng.integers(0, shape * shape // 2), replace=False)
+        for t, a in enumerate(stones):
+            b[k, t % 2, a] = 1
+    return b.reshape(n, 2, shape, shape)
+
+
+@pytest.mark.parametrize("shape,front,pol,val,n", [(15, 4, 2, 2, 300), (13, 4, 2, 2, 50), (20, 3, 1, 2, 40),
+                                                     (7, 1, 0, 0, 9), (5, 2, 3, 1, 1100)])
+def test_fused_net_matches_torch_float64(shape, front, pol, val, n):
+    import torch
+    from alphazero_amd.evaluator import FusedNetEvaluator
+
+    m = _model(shape, front, pol, val, 3)
+    boards = _boards(n, shape, 5)
+    with torch.no_grad():
+        v_ref, lp_ref = m.double()(torch.from_numpy(boards).double())
+    ev = FusedNetEvaluator(m.float(), shape)
+    v, lp = ev(torch.from_numpy(boards).cuda())
+    v, lp = v.cpu().numpy(), lp.cpu().numpy()
+    assert v.shape == (n,) and lp.shape == (n, shape * shape)
+    assert np.abs(v - v_ref.reshape(-1).numpy()).max() < 2e-5
+    assert np.abs(lp - lp_ref.numpy()).max() < 2e-5
+    assert np.allclose(np.exp(lp.astype(np.float64)).sum(axis=1), 1.0, atol=1e-5)
+
+
+def test_fused_net_drives_a_search():
+    import torch
+    from alphazero_amd import selfplay as sp
+    from alphazero_amd.evaluator import FusedNetEvaluator, TorchEvaluator
+
+    S, G, sims = 9, 6, 40
+    m = _model(S, 4, 2, 2, 1)
+    fused = sp.TreeBatch(G, S, FusedNetEvaluator(m, S), cpuct=4.0, eps=0.0, nodes_per_tree=sims * 4)
+    ref = sp.TreeBatch(G, S, TorchEvaluator(m), cpuct=4.0, eps=0.0, nodes_per_tree=sims * 4)
+    for b in (fused, ref):
+        b.make_move(np.arange(G, dtype=np.int32) * 3)
+        b.simulate(sims)
+    # same network, two float32 evaluation orders: the visit distributions agree closely
+    assert np.abs(fused.probs() - ref.probs()).max() < 0.08
+    assert (fused.probs().argmax(axis=1) == ref.probs().argmax(axis=1)).mean() >= 0.5
+    fused.close()
+    ref.close()

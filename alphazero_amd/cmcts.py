@@ -182,8 +182,8 @@ class mcts:
         if self._evaluator is None:
             if not self._params:
                 raise RuntimeError("Predictor missing!")  # cmcts.cpp:89-91
-            from .evaluator import TorchScriptEvaluator
-            self._evaluator = TorchScriptEvaluator(self._params, self._device)
+            from .evaluator import load_evaluator
+            self._evaluator = load_evaluator(self._params, self._shape, self._device)
         return self._evaluator
 
     def _ensure_noise(self, rows):

@@ -77,6 +77,18 @@ class FusedNetEvaluator:
         self.params = packed.to(self.device)
 
     @staticmethod
+    def supports(state):
+        """True when `state` (a state_dict) is the reference architecture this kernel is built for."""
+        try:
+            w0 = state["front.0.weight"]
+            return (tuple(w0.shape[:2]) == (16, 2) and tuple(w0.shape[2:]) == (3, 3)
+                    and tuple(state["policy.0.weight"].shape) == (1, 16, 3, 3)
+                    and tuple(state["value.0.weight"].shape) == (1, 16, 1, 1)
+                    and "front.1.running_mean" in state)
+        except KeyError:
+            return False
+
+    @staticmethod
     def _fold(state, prefix, i):
         """conv weight + inference batch norm of block i of a Sequential (conv at 3i, bn at 3i+1)."""
         w = state[f"{prefix}.{3 * i}.weight"].detach().double().cpu()
@@ -134,3 +146,15 @@ class FusedNetEvaluator:
         if rc != 0:
             raise RuntimeError(f"az_net_eval failed (code {rc})")
         return value, logp
+
+
+def load_evaluator(path, shape, device=0):
+    """Evaluator for the TorchScript file the reference hands to cmcts
+    (src/self_play.py:62-72): the fused kernel when the file holds the reference
+    architecture, the PyTorch module otherwise."""
+    dev = torch.device("cuda", device) if not isinstance(device, torch.device) else device
+    module = torch.jit.load(path, map_location=dev)
+    state = module.state_dict()
+    if FusedNetEvaluator.supports(state):
+        return FusedNetEvaluator(state, shape, dev, name=path)
+    return TorchEvaluator(module, dev, name=path)

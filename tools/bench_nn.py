@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Stepped search with a batched policy/value network (not the headline bench).
 
-    python tools/bench_nn.py [--trees 8192] [--shape 15] [--sims 64] [--moves 2]
+    python tools/bench_nn.py [--trees 8192] [--shape 15] [--sims 64] [--moves 2] [--evaluator fused|torch]
 
 Many concurrent trees, one leaf per tree per search step packed into a single
-PyTorch-ROCm forward of a random-init PolicyValueNet (seed 0); reports
+network evaluation (random-init PolicyValueNet, seed 0; the library's fused
+kernel or a PyTorch-ROCm forward); reports
 simulations/s and how the step time splits between the tree kernels
 (az_select + az_expand_backup) and the evaluator.
 """
@@ -28,17 +29,22 @@ def main():
     ap.add_argument("--moves", type=int, default=2)
     ap.add_argument("--nodes", type=int, default=1024)
     ap.add_argument("--dtype", default="float32", choices=["float32", "bfloat16"])
+    ap.add_argument("--evaluator", default="fused", choices=["fused", "torch"],
+                    help="fused = the library's own f32 matrix-core kernel, torch = PyTorch-ROCm (MIOpen)")
     args = ap.parse_args()
     import torch
 
     from alphazero_amd import selfplay as sp
-    from alphazero_amd.evaluator import TorchEvaluator
+    from alphazero_amd.evaluator import FusedNetEvaluator, TorchEvaluator
     from alphazero_amd.model import PolicyValueNet
 
     torch.manual_seed(0)
     dev = torch.device("cuda", 0)
     net = PolicyValueNet(args.shape).eval()
-    if args.dtype == "bfloat16":
+    if args.evaluator == "fused":
+        ev = FusedNetEvaluator(net, args.shape, dev)
+        args.dtype = "float32"
+    elif args.dtype == "bfloat16":
         net = net.to(torch.bfloat16)
 
         class Bf16Eval(TorchEvaluator):
@@ -85,7 +91,7 @@ def main():
     st = eng.get_stats()
     print(json.dumps({
         "workload": f"{args.shape}x{args.shape}, {args.trees} concurrent trees, random-init conv policy/value net "
-                    f"({args.dtype}), batched leaf evaluation, eps=0.25",
+                    f"({args.evaluator}, {args.dtype}), batched leaf evaluation, eps=0.25",
         "sims_per_s": args.trees * n_steps / wall,
         "ms_per_step": wall / n_steps * 1e3,
         "tree_kernels_ms_per_step": t_tree / n_steps,

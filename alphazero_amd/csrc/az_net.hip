@@ -44,18 +44,28 @@ constexpr int LAYER_FLOATS = 36 * 64 + 32;
 constexpr int POLICY_FLOATS = 9 * CH + 1;
 constexpr int VALUE_FLOATS = CH + 1;
 
+// parameters of one convolution as each lane needs them: its B operands (one per
+// K step) and the folded batch-norm scale/shift of its output channel
+template <int KSTEPS> struct LayerRegs {
+    float b[KSTEPS];
+    float sc, sh;
+};
+template <int KSTEPS> __device__ __forceinline__ void load_layer(const float *prm, int lane, LayerRegs<KSTEPS> &w)
+{
+#pragma unroll
+    for (int i = 0; i < KSTEPS; i++) w.b[i] = prm[i * 64 + lane];
+    w.sc = prm[KSTEPS * 64 + (lane & 15)];
+    w.sh = prm[KSTEPS * 64 + 16 + (lane & 15)];
+}
+
 // one 3x3 convolution + folded batch norm + ReLU, `in` -> `out` (LDS planes).
 // KSTEPS = 36 for 16 input channels (tap-major, 4 channels per step), 5 for the
 // 2-plane input layer (K index = tap*2 + plane, padded with zero weights).
 template <int S, int KSTEPS>
-__device__ __forceinline__ void conv3x3(const float *in, float *out, const float *prm, int wave, int lane)
+__device__ __forceinline__ void conv3x3(const float *in, float *out, const LayerRegs<KSTEPS> &w, int wave, int lane)
 {
     using G = Geo<S>;
-    float b[KSTEPS];
-#pragma unroll
-    for (int i = 0; i < KSTEPS; i++) b[i] = prm[i * 64 + lane];
     const int co = lane & 15, kq = lane >> 4;
-    const float sc = prm[KSTEPS * 64 + co], sh = prm[KSTEPS * 64 + 16 + co];
     for (int tile0 = wave * 4; tile0 < G::NT; tile0 += 16) {
         f32x4 acc[4];
         int base[4];
@@ -74,7 +84,7 @@ __device__ __forceinline__ void conv3x3(const float *in, float *out, const float
             const int off = ci * G::PS + (tap / 3 - 1) * G::ROW + (tap % 3 - 1);
 #pragma unroll
             for (int t = 0; t < 4; t++)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(in[base[t] + off], b[ks], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(in[base[t] + off], w.b[ks], acc[t], 0, 0, 0);
         }
 #pragma unroll
         for (int t = 0; t < 4; t++) {
@@ -83,14 +93,50 @@ __device__ __forceinline__ void conv3x3(const float *in, float *out, const float
                 const int y = tile / G::TPR, x0 = (tile % G::TPR) * 16 + kq * 4;
 #pragma unroll
                 for (int r = 0; r < 4; r++)
-                    if (x0 + r < S) out[co * G::PS + (y + 1) * G::ROW + x0 + r + 1] = fmaxf(acc[t][r] * sc + sh, 0.f);
+                    if (x0 + r < S)
+                        out[co * G::PS + (y + 1) * G::ROW + x0 + r + 1] = fmaxf(acc[t][r] * w.sc + w.sh, 0.f);
             }
         }
     }
 }
 
+// policy head: 3x3 conv to one channel + bias, log-softmax over the board
 template <int S>
-__global__ __launch_bounds__(256) void k_net_eval(const float *boards, int n, const float *prm, int front, int pol,
+__device__ __forceinline__ void policy_head(const float *src, const float *p_policy, float *red, float *logit,
+                                            float *logp_row, int tid, int wave, int lane)
+{
+    using G = Geo<S>;
+    float lmax = -INFINITY;
+    for (int p = tid; p < G::SIZE; p += 256) {
+        const int ctr = (p / S + 1) * G::ROW + p % S + 1;
+        float acc = p_policy[9 * CH];
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int off = ctr + (tap / 3 - 1) * G::ROW + (tap % 3 - 1);
+#pragma unroll
+            for (int ci = 0; ci < CH; ci++) acc += p_policy[tap * CH + ci] * src[ci * G::PS + off];
+        }
+        logit[p] = acc;
+        lmax = fmaxf(lmax, acc);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    lmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float lsum = 0.f;
+    for (int p = tid; p < G::SIZE; p += 256) lsum += expf(logit[p] - lmax);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) lsum += __shfl_xor(lsum, o);
+    if (lane == 0) red[4 + wave] = lsum;
+    __syncthreads();
+    const float lse = lmax + logf((red[4] + red[5]) + (red[6] + red[7]));
+    for (int p = tid; p < G::SIZE; p += 256) logp_row[p] = logit[p] - lse;
+    __syncthreads(); // scratch and the branch buffers are free again
+}
+
+template <int S>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_eval(const float *boards, int n, const float *prm, int front, int pol,
                                                   int val, float *value_out, float *logp_out)
 {
     using G = Geo<S>;
@@ -101,79 +147,61 @@ __global__ __launch_bounds__(256) void k_net_eval(const float *boards, int n, co
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int i = tid; i < 3 * CH * G::PS; i += 256) lds[i] = 0.f; // halos stay zero from here on
     __syncthreads();
+    const int nl = front - 1 + pol + val; // 16->16 layers: trunk, policy branch, value branch
     const float *p_layers = prm + FIRST_FLOATS;
-    const float *p_policy = p_layers + (size_t)(front - 1 + pol + val) * LAYER_FLOATS;
+    const float *p_policy = p_layers + (size_t)nl * LAYER_FLOATS;
     const float *p_value = p_policy + POLICY_FLOATS;
+    // Buffers: the input layer writes B, the trunk ping-pongs B <-> A and leaves
+    // `front` in F; X is the other one of {A, B}.  Each branch runs F -> X -> C -> X ...
+    float *F = ((front - 1) & 1) ? A : B;
+    float *X = ((front - 1) & 1) ? B : A;
+    const int head_at = front - 1 + pol; // 16->16 layers done when the policy head runs
+    LayerRegs<5> w0;
+    load_layer<5>(prm, lane, w0);
 
     for (int pos = blockIdx.x; pos < n; pos += gridDim.x) {
-        // raw planes into channels 0..1 of A
+        // raw planes into channels 0..1 of A (channels 2..15 of A may hold stale
+        // interior values of the previous position: the 2-plane layer never reads them)
         for (int i = tid; i < CIN * G::SIZE; i += 256) {
             const int c = i / G::SIZE, p = i - c * G::SIZE;
             A[c * G::PS + (p / S + 1) * G::ROW + p % S + 1] = boards[(size_t)pos * CIN * G::SIZE + i];
         }
+        // The parameters of the next convolution are requested one layer ahead, so
+        // their L2 latency runs under the current layer's matrix instructions.
+        LayerRegs<36> wq, wn;
+        if (nl > 0) load_layer<36>(p_layers, lane, wq);
         __syncthreads();
-        // trunk: A -> B -> A -> ... ; `cur` ends up holding `front`
-        float *cur = A, *nxt = B;
-        conv3x3<S, 5>(cur, nxt, prm, wave, lane);
+        conv3x3<S, 5>(A, B, w0, wave, lane);
         __syncthreads();
-        { float *t = cur; cur = nxt; nxt = t; }
-        for (int l = 0; l < front - 1; l++) {
-            conv3x3<S, 36>(cur, nxt, p_layers + (size_t)l * LAYER_FLOATS, wave, lane);
-            __syncthreads();
-            float *t = cur; cur = nxt; nxt = t;
-        }
-        // policy branch: cur (kept) -> nxt -> C -> nxt ...
-        const float *src = cur;
-        float *d0 = nxt, *d1 = C;
-        for (int l = 0; l < pol; l++) {
-            conv3x3<S, 36>(src, d0, p_layers + (size_t)(front - 1 + l) * LAYER_FLOATS, wave, lane);
-            __syncthreads();
-            src = d0;
-            float *t = d0; d0 = d1; d1 = t;
-        }
-        // policy head: 3x3 conv to one channel + bias, log-softmax over the board
-        float lmax = -INFINITY;
-        for (int p = tid; p < G::SIZE; p += 256) {
-            const int ctr = (p / S + 1) * G::ROW + p % S + 1;
-            float acc = p_policy[9 * CH];
-#pragma unroll
-            for (int tap = 0; tap < 9; tap++) {
-                const int off = ctr + (tap / 3 - 1) * G::ROW + (tap % 3 - 1);
-#pragma unroll
-                for (int ci = 0; ci < CH; ci++) acc += p_policy[tap * CH + ci] * src[ci * G::PS + off];
+        const float *head_src = F; // what the policy / value heads read when their branch is empty
+        if (head_at == 0) policy_head<S>(F, p_policy, red, logit, logp_out + (size_t)pos * G::SIZE, tid, wave, lane);
+        for (int l = 0; l < nl; l++) {
+            if (l + 1 < nl) load_layer<36>(p_layers + (size_t)(l + 1) * LAYER_FLOATS, lane, wn);
+            const float *src;
+            float *dst;
+            if (l < front - 1) { // trunk
+                src = (l & 1) ? A : B;
+                dst = (l & 1) ? B : A;
+            } else {             // branch layer j
+                const int j = l - (front - 1) - (l >= front - 1 + pol ? pol : 0);
+                src = j == 0 ? F : ((j & 1) ? X : C);
+                dst = (j & 1) ? C : X;
             }
-            logit[p] = acc;
-            lmax = fmaxf(lmax, acc);
-        }
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
-        if (lane == 0) red[wave] = lmax;
-        __syncthreads();
-        lmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        float lsum = 0.f;
-        for (int p = tid; p < G::SIZE; p += 256) lsum += expf(logit[p] - lmax);
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) lsum += __shfl_xor(lsum, o);
-        if (lane == 0) red[4 + wave] = lsum;
-        __syncthreads();
-        const float lse = lmax + logf((red[4] + red[5]) + (red[6] + red[7]));
-        for (int p = tid; p < G::SIZE; p += 256) logp_out[(size_t)pos * G::SIZE + p] = logit[p] - lse;
-        __syncthreads(); // `red`, `logit` and the policy buffers are free again
-        // value branch: front (cur) -> ... ; the policy buffers are reused
-        src = cur;
-        d0 = nxt; d1 = C;
-        for (int l = 0; l < val; l++) {
-            conv3x3<S, 36>(src, d0, p_layers + (size_t)(front - 1 + pol + l) * LAYER_FLOATS, wave, lane);
+            conv3x3<S, 36>(src, dst, wq, wave, lane);
             __syncthreads();
-            src = d0;
-            float *t = d0; d0 = d1; d1 = t;
+            head_src = dst;
+            if (l + 1 == head_at) {
+                policy_head<S>(head_src, p_policy, red, logit, logp_out + (size_t)pos * G::SIZE, tid, wave, lane);
+                head_src = F; // the value branch starts from the trunk output again
+            }
+            if (l + 1 < nl) wq = wn;
         }
-        // value head: 1x1 conv + bias, board average, tanh
+        // ---- value head: 1x1 conv + bias, board average, tanh
         float vs = 0.f;
         for (int p = tid; p < G::SIZE; p += 256) {
             const int ctr = (p / S + 1) * G::ROW + p % S + 1;
 #pragma unroll
-            for (int ci = 0; ci < CH; ci++) vs += p_value[ci] * src[ci * G::PS + ctr];
+            for (int ci = 0; ci < CH; ci++) vs += p_value[ci] * head_src[ci * G::PS + ctr];
         }
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) vs += __shfl_xor(vs, o);
@@ -181,10 +209,6 @@ __global__ __launch_bounds__(256) void k_net_eval(const float *boards, int n, co
         __syncthreads();
         if (tid == 0) value_out[pos] = tanhf(((red[0] + red[1]) + (red[2] + red[3])) / (float)G::SIZE + p_value[CH]);
         __syncthreads();
-        // stale activations of this position sit only in interior cells, which the
-        // next position overwrites before reading (channels 0..1 of A by the input
-        // copy; every other plane by the layer that produces it)... except channels
-        // 2..15 of A, which the 2-plane input layer never reads.
     }
 }
 

@@ -534,11 +534,9 @@ __device__ __forceinline__ void runner_up(const NodeRegs<E> &R, const Cand &c, c
 template <int WPT, int E>
 __device__ __forceinline__ Pick finish_pick(const Cand &c, int tid, Slot *slots, int &phase)
 {
-    // (tid >> 6 rather than a literal 0 for WPT == 1 on purpose: a pick the compiler
-    // can prove wave-uniform turns the search loop into scalar branches, and with one
-    // wavefront per SIMD the taken branches cost more than the exec-masked
-    // fall-through code: 7900 vs 6900 cycles per search measured on MI355X)
-    const int lane = tid & 63, wave = tid >> 6;
+    // (a literal 0 for one wavefront per tree makes the pick provably wave-uniform,
+    // so the search loop compiles to scalar branches instead of exec-mask code)
+    const int lane = tid & 63, wave = WPT == 1 ? 0 : tid >> 6;
     double m;
     const unsigned long long mask = wave_argmax_f64(c.u, c.k >= 0, m);
     Pick pk;
@@ -800,24 +798,24 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
 
     double sq_root = sqrt_node_n(root_n, s_sqrt); // sqrt(nodeN + 1e-8) of the root, kept one search ahead
 
-    int worker_left = 0;
-    for (int i = 0; i < A.n_total && err == 0; ++i) {
-        if (AZ_UNLIKELY(worker_left == 0)) { // new worker, new generator (cmcts.cpp:132-133)
-            noise_row = 0;
-            worker_left = A.per_worker > 0 ? A.per_worker : A.n_total;
-        }
-        worker_left--;
-        WState s = root_state;
-
-        if (AZ_UNLIKELY(root < 0)) {
-            // first search on a fresh root only expands it (cmcts.cpp:190-243)
-            if (free_top == 0) { err = AZ_ERR_POOL_FULL; break; }
-            if (MIX != 0 && P.noise != nullptr && noise_row >= P.noise_rows) { err = AZ_ERR_NOISE_ROWS; break; }
+    // A fresh root is expanded by the first search of the call, which does nothing
+    // else (cmcts.cpp:190-243).  That search is taken out of the loop: inside it the
+    // rewrite of every root register would be carried around each iteration.
+    int worker_left = 0, first = 0;
+    if (root < 0 && A.n_total > 0) {
+        noise_row = 0;
+        worker_left = (A.per_worker > 0 ? A.per_worker : A.n_total) - 1;
+        first = 1;
+        if (free_top == 0) {
+            err = AZ_ERR_POOL_FULL;
+        } else if (MIX != 0 && P.noise != nullptr && noise_row >= P.noise_rows) {
+            err = AZ_ERR_NOISE_ROWS;
+        } else {
             const int slot = pop_free(P, tbase, free_top, fs_batch, fs_pos, tid);
             if (tid == 0) { P.order[tbase + n_order] = slot; P.parent[tbase + slot] = -1; }
             n_order++;
             float pr[E];
-            (void)evaluate<E, EVAL>(A, s, tid, pr);
+            (void)evaluate<E, EVAL>(A, root_state, tid, pr);
             mix_prior<E, MIX>(P, pr, false, noise_row, tid, R.p);
             if (MIX != 0 && P.noise != nullptr) noise_row++;
             st_f64<E>(arena_ptr(P, tree), rec_off(slot) + OFF_P, tid, R.p);
@@ -831,8 +829,15 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             root = slot;
             n_exp++; n_sims++;
             __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): noise loads into the root registers are complete
-            continue;
         }
+    }
+    for (int i = first; i < A.n_total && err == 0; ++i) {
+        if (AZ_UNLIKELY(worker_left == 0)) { // new worker, new generator (cmcts.cpp:132-133)
+            noise_row = 0;
+            worker_left = A.per_worker > 0 ? A.per_worker : A.n_total;
+        }
+        worker_left--;
+        WState s = root_state;
 
         // level 0: the root, in registers
         STAMP(7);
@@ -912,10 +917,11 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
                     } else if (tid == pk.a / E) {
                         *reinterpret_cast<int *>(arena_ptr(P, tree) + (rec_off(cur) + OFF_N + (unsigned)pk.a * 4u)) = pk.n + 1;
                     }
+                    // (lane == depth matches no lane once depth >= 64: the register write is
+                    // then a no-op and needs no branch of its own)
+                    path_put(path, depth, cur, pk.a, pk.w - 1. /* virtual loss */, tid & 63);
                     if (AZ_UNLIKELY(depth >= 64)) {
                         s_node[depth - 64] = cur; s_act[depth - 64] = pk.a; s_w1[depth - 64] = pk.w - 1.;
-                    } else {
-                        path_put(path, depth, cur, pk.a, pk.w - 1. /* virtual loss */, tid & 63);
                     }
                     depth++;
                     parent_slot = cur;

@@ -256,16 +256,22 @@ template <int E> __device__ __forceinline__ void st_f64(char *base, unsigned off
     }
 }
 
-// node with nodeN > 0: all four arrays; fresh node (nodeN == 0): only P exists
-template <int E>
+// node with nodeN > 0: all four arrays; fresh node (nodeN == 0): only P exists.
+// ZERO_FRESH = false leaves n/link/w of a fresh node unset for callers that never
+// read them then: writing the zeros would first have to wait (s_waitcnt vmcnt(0))
+// for every load still in flight into those registers, the P load just issued
+// included, and the latency overlap with the rules code would be gone.
+template <int E, bool ZERO_FRESH = true>
 __device__ __forceinline__ void load_node(const AzParams &P, int tree, int slot, int tid, bool fresh, NodeRegs<E> &nd)
 {
     const char *arena = arena_ptr(P, tree);
     const unsigned ro = rec_off(slot);
     ld_f64<E>(arena, ro + OFF_P, tid, nd.p);
     if (fresh) {
+        if constexpr (ZERO_FRESH) {
 #pragma unroll
-        for (int k = 0; k < E; k++) { nd.n[k] = 0; nd.link[k] = 0; nd.w[k] = 0.; }
+            for (int k = 0; k < E; k++) { nd.n[k] = 0; nd.link[k] = 0; nd.w[k] = 0.; }
+        }
     } else {
         ld_i32<E>(arena, ro + OFF_N, tid, nd.n);
         ld_i32<E>(arena, ro + OFF_LINK, tid, nd.link);
@@ -600,6 +606,11 @@ __device__ __forceinline__ Pick select_pick(const NodeRegs<E> &nd, bool fresh, d
 // sqrt(nodeN + 1e-8) (node.cpp:106,108): a table of the same fp64 operation for
 // the first SQ_TAB values (nodeN is an integer), the operation itself beyond
 constexpr int SQ_TAB = 2048;
+__device__ __forceinline__ double sqrt_from_table(int node_n, const double *tab) // tab: an LDS table, never null
+{
+    if (AZ_LIKELY(node_n < SQ_TAB)) return tab[node_n];
+    return __dsqrt_rn((double)node_n + 1e-8);
+}
 __device__ __forceinline__ double sqrt_node_n(int node_n, const double *tab)
 {
     if (AZ_LIKELY(tab != nullptr && node_n < SQ_TAB)) return tab[node_n];
@@ -796,7 +807,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
     int fs_batch = 0, fs_pos = 64;
     STAMP_DECL
 
-    double sq_root = sqrt_node_n(root_n, s_sqrt); // sqrt(nodeN + 1e-8) of the root, kept one search ahead
+    double sq_root = sqrt_from_table(root_n, s_sqrt); // sqrt(nodeN + 1e-8) of the root, kept one search ahead
 
     // A fresh root is expanded by the first search of the call, which does nothing
     // else (cmcts.cpp:190-243).  That search is taken out of the loop: inside it the
@@ -825,7 +836,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
                 C.cp[k] = P.cpuct * R.p[k]; C.np1[k] = 1.; C.rinv[k] = 1.; C.q[k] = 0.;
             }
             root_n = 0;
-            sq_root = sqrt_node_n(0, s_sqrt);
+            sq_root = sqrt_from_table(0, s_sqrt);
             root = slot;
             n_exp++; n_sims++;
             __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): noise loads into the root registers are complete
@@ -867,7 +878,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             R.w[k] -= one;
         }
         root_n += 1;
-        sq_root = sqrt_node_n(root_n, s_sqrt); // for the next search: the table read overlaps this one
+        sq_root = sqrt_from_table(root_n, s_sqrt); // for the next search: the table read overlaps this one
 
         int depth = 0;           // path entries below the root
         int parent_slot = root;  // node that will own the link to a new child
@@ -885,7 +896,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             const int nn = pk.n - 1;
             const bool fresh = nn == 0;
             NodeRegs<E> nd;
-            if (cur >= 0) load_node<E>(P, tree, cur, tid, fresh, nd);
+            if (cur >= 0) load_node<E, false>(P, tree, cur, tid, fresh, nd);
             state_move<E>(s, pk.a, tid);
             STAMP(1);
             if (AZ_UNLIKELY(s.winner != -1.f)) { // cmcts.cpp:253-267: no node for a finished game
@@ -897,7 +908,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
                 __builtin_amdgcn_s_waitcnt(0x0F70);
                 STAMP(2);
 #endif
-                pk = select_pick<WPT, E>(nd, fresh, sqrt_node_n(nn, s_sqrt), s.occ, P.cpuct, tid, s_slots, phase);
+                pk = select_pick<WPT, E>(nd, fresh, sqrt_from_table(nn, s_sqrt), s.occ, P.cpuct, tid, s_slots, phase);
                 STAMP(3);
                 if (AZ_UNLIKELY(pk.a < 0)) {
                     leaf = NO_ACTION;

@@ -869,13 +869,17 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
         const bool root_owner = tid == root_a / E;
         // the visit and the virtual loss (node.cpp:116-118) of the picked action,
         // as additions of 0 or 1 (x + 0.0 and x - 0.0 are x for these values)
+        {
+            const int root_k = root_a % E; // wave-uniform: only the matching registers are touched
+            const double one = root_owner ? 1. : 0.;
+            const int onei = root_owner ? 1 : 0;
 #pragma unroll
-        for (int k = 0; k < E; k++) {
-            const bool hit = root_owner && k == root_a % E;
-            const double one = hit ? 1. : 0.;
-            R.n[k] += hit ? 1 : 0;
-            C.np1[k] += one;
-            R.w[k] -= one;
+            for (int k = 0; k < E; k++)
+                if (root_k == k) {
+                    R.n[k] += onei;
+                    C.np1[k] += one;
+                    R.w[k] -= one;
+                }
         }
         root_n += 1;
         sq_root = sqrt_from_table(root_n, s_sqrt); // for the next search: the table read overlaps this one

@@ -331,6 +331,57 @@ def eval_games(best, latest, sims_best, sims_latest, init_moves=()):
     return wins_best, wins_latest, draws
 
 
+def eval_games_device(best, latest, sims_best, sims_latest, init_moves=()):
+    """eval_games with the move decision on the GPU (az_choose_moves, greedy): per
+    half-move the host only reads the winners.  Same tallies as eval_games."""
+    torch = best.torch
+    G, size = best.n_trees, best.size
+    assert latest.n_trees == G
+    dev = best.dev
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for m in init_moves:
+        best.make_move(np.full(G, m, np.int32))
+        latest.make_move(np.full(G, m, np.int32))
+    first_player = int(best.eng.get_state(0)[0]) if G else 0  # src/eval.py:105
+    second_player = 1 - first_player
+    best_opens = (np.arange(G) % 2) == 0
+    alive = np.ones(G, bool)
+    act_b = torch.empty(G, dtype=torch.int32, device=dev)
+    act_l = torch.empty(G, dtype=torch.int32, device=dev)
+    for _ in range(size):
+        for half in (0, 1):
+            if not alive.any():
+                break
+            best_to_move = best_opens if half == 0 else ~best_opens
+            act_b.fill_(-1)
+            act_l.fill_(-1)
+            for batch, mine, sims, d_act in ((best, best_to_move, sims_best, act_b),
+                                             (latest, ~best_to_move, sims_latest, act_l)):
+                mask = alive & mine
+                if not mask.any():
+                    continue
+                batch.simulate(sims, mask)  # leaves exactly these trees active
+                batch.eng.choose_moves(None, True, d_act.data_ptr(), None, None, stream)
+            act = torch.maximum(act_b, act_l)  # every live game was searched by exactly one side
+            try:
+                best.eng.make_move_device(act.data_ptr(), stream)
+                latest.eng.make_move_device(act.data_ptr(), stream)
+                latest.eng.sync_check(stream)
+                winner = best.eng.sync_states(stream)[2]
+            except _E.EngineError as e:
+                raise RuntimeError(str(e)) from None
+            alive &= winner == -1.0
+        if not alive.any():
+            break
+    winner = best.winners()
+    opener_won = winner == first_player
+    other_won = winner == second_player
+    draws = int((~(opener_won | other_won)).sum())
+    wins_best = int((opener_won & best_opens).sum() + (other_won & ~best_opens).sum())
+    wins_latest = int((opener_won & ~best_opens).sum() + (other_won & best_opens).sum())
+    return wins_best, wins_latest, draws
+
+
 def promote(wins_best, wins_latest, threshold=0.6):
     """src/eval.py:176-180 with EVAL_TRESHOLD (general_config.py:24)."""
     return wins_latest / (wins_latest + wins_best) >= threshold

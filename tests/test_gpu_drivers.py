@@ -79,7 +79,8 @@ def test_self_play_sampled_moves_single_game():
     b1.close()
 
 
-def test_eval_games_match_reference_loop():
+@pytest.mark.parametrize("driver", ["host", "device"])
+def test_eval_games_match_reference_loop(driver):
     from alphazero_amd import selfplay as sp
 
     S, size, G = 7, 49, 6
@@ -102,7 +103,7 @@ def test_eval_games_match_reference_loop():
         act = np.array([O.opening(size, g * 3 + 2)[ply] for g in range(G)], np.int32)
         best.make_move(act)
         latest.make_move(act)
-    wb, wl, dr = sp.eval_games(best, latest, sims_b, sims_l)
+    wb, wl, dr = (sp.eval_games if driver == "host" else sp.eval_games_device)(best, latest, sims_b, sims_l)
     ev_b = oracle_exact_evaluator(S)
     ev_l = O.callback_evaluator(shifted_numpy, S, log_priors=False)
     exp = [0, 0, 0]

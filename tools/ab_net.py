@@ -1,0 +1,25 @@
+import sys, os, statistics, subprocess
+sys.path.insert(0, '/root/repo')
+if len(sys.argv) > 2 and sys.argv[1] == 'child':
+    import torch, numpy as np
+    from alphazero_amd import engine as E
+    E.LIB_PATH = os.path.join('/root/repo/alphazero_amd', sys.argv[2])
+    from alphazero_amd.evaluator import FusedNetEvaluator
+    from alphazero_amd.model import PolicyValueNet
+    S = int(sys.argv[3])
+    torch.manual_seed(0)
+    ev = FusedNetEvaluator(PolicyValueNet(S).eval(), S)
+    b = (torch.rand(8192, 2, S, S, device='cuda') < 0.2).float()
+    for _ in range(3): ev(b)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(20):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); ev(b); e1.record(); e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    print(statistics.median(ts))
+else:
+    for S in (15, 20):
+        for lib in sys.argv[1:]:
+            out = subprocess.run([sys.executable, __file__, 'child', lib, str(S)], capture_output=True, text=True)
+            print(S, lib, out.stdout.strip().splitlines()[-1] if out.returncode == 0 else out.stderr[-300:])

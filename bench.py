@@ -82,18 +82,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs for a one-GPU box: AZ_BENCH_DEVICE pins every rank to one
+    # card, AZ_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks per GPU)
+    backend = os.environ.get("AZ_BENCH_BACKEND", "nccl")
+    dev_index = int(os.environ.get("AZ_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    cdev = dev if backend == "nccl" else torch.device("cpu")
 
     from alphazero_amd import engine as E
 
     B = args.trees
-    eng = E.Engine(B, SHAPE, nodes_per_tree=NODES_PER_TREE, cpuct=CPUCT, device=local_rank)
+    eng = E.Engine(B, SHAPE, nodes_per_tree=NODES_PER_TREE, cpuct=CPUCT, device=dev_index)
     eng.set_alpha_default()
     eng.set_eps(0.0)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -152,7 +160,7 @@ def main():
     used, max_used = eng.pool_usage(0)
     sims_local = st["sims"]
     depth = st["select_calls"] / max(1, st["sims"])
-    vals = torch.tensor([elapsed, float(sims_local), float(st["select_calls"])], dtype=torch.float64, device=dev)
+    vals = torch.tensor([elapsed, float(sims_local), float(st["select_calls"])], dtype=torch.float64, device=cdev)
     if dist is not None:
         tmax = vals.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -725,7 +725,11 @@ __device__ __forceinline__ int pop_free(const AzParams &P, size_t tbase, int &fr
 #ifdef AZ_STAMPS
 #define STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = __builtin_readcyclecounter();
 #define STAMP(i) do { unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_t; st_t = t_; } while (0)
-#define STAMP_FLUSH(tree) do { if (tid == 0 && P.stamps) for (int q = 0; q < 8; q++) P.stamps[(size_t)(tree) * 8 + q] = st_acc[q]; } while (0)
+// (bits 40.. of entries 6 and 7 carry the XCC_ID and HW_ID registers: where the wavefront ran)
+#define STAMP_FLUSH(tree) do { if (tid == 0 && P.stamps) { \
+        st_acc[6] |= (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) << 40; \
+        st_acc[7] |= (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff) << 40; \
+        for (int q = 0; q < 8; q++) P.stamps[(size_t)(tree) * 8 + q] = st_acc[q]; } } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(i) do { } while (0)

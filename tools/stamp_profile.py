@@ -35,7 +35,25 @@ def main():
         ms = eng.timing_end()
         out = np.zeros((trees, 8), np.uint64)
         eng._check(eng.L.az_debug_stamps(eng.h, out.ctypes.data))
-        tot = out.sum(axis=1).mean()
+        xcc = (out[:, 6] >> np.uint64(40)).astype(np.int64)
+        hw = (out[:, 7] >> np.uint64(40)).astype(np.int64)
+        out &= np.uint64((1 << 40) - 1)
+        per_tree = out.sum(axis=1)
+        # placement: HW_ID = wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]
+        simd_key = xcc * 65536 + (hw & 0xff30)
+        cu_key = xcc * 65536 + (hw & 0xff00)
+        _, per_simd = np.unique(simd_key, return_counts=True)
+        _, per_cu = np.unique(cu_key, return_counts=True)
+        print(f"placement: {len(per_simd)} SIMDs used (max {per_simd.max()} trees on one), "
+              f"{len(per_cu)} CUs used (max {per_cu.max()}), XCCs {np.bincount(xcc).tolist()}")
+        pt = np.sort(per_tree)
+        print(f"cycles per tree: min {pt[0]} p10 {pt[len(pt) // 10]} median {pt[len(pt) // 2]} "
+              f"p90 {pt[len(pt) * 9 // 10]} max {pt[-1]}")
+        for cnt in np.unique(per_simd):
+            keys = np.unique(simd_key)[per_simd == cnt]
+            sel = np.isin(simd_key, keys)
+            print(f"   trees sharing a SIMD with {cnt - 1} others: {sel.sum()}, mean cycles {per_tree[sel].mean():.0f}")
+        tot = per_tree.mean()
         print(f"launch {it}: {ms:.3f} ms, mean cycles/tree {tot:.0f} ({tot / 800:.0f} per search)")
         for n, v in zip(NAMES, out.mean(axis=0)):
             print(f"   {n:16s} {v / 800:8.0f} cycles/search  {100 * v / tot:5.1f} %")

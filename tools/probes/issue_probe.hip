@@ -36,6 +36,13 @@ PROBE(k_dpp_dep, REP64(asm volatile("s_nop 1\n v_max_i32_dpp %0, %0, %0 quad_per
 PROBE(k_branch_taken, REP64(asm volatile("s_cmp_eq_u32 %0, 12345\n s_cbranch_scc1 1f\n v_add_u32 %1, %1, 1\n s_branch 2f\n 1: v_add_u32 %1, %1, 2\n 2:" : "+s"(sa), "+v"(ia) :: "scc");))
 PROBE(k_branch_nottaken, REP64(asm volatile("s_cmp_eq_u32 %0, 12345\n s_cbranch_scc1 1f\n v_add_u32 %1, %1, 1\n 1:" : "+s"(sa), "+v"(ia) :: "scc");))
 PROBE(k_execz_skip, REP64(asm volatile("v_cmp_eq_u32 vcc, 12345, %0\n s_and_saveexec_b64 s[20:21], vcc\n s_cbranch_execz 1f\n v_add_u32 %0, %0, 1\n 1: s_or_b64 exec, exec, s[20:21]" : "+v"(ia) :: "vcc", "scc", "s20", "s21");))
+// taken branches whose target lies further ahead in the code (skipped filler = s_nop words)
+PROBE(k_far64, REP64(asm volatile("s_branch 1f\n .fill 16, 4, 0xbf800000\n 1: v_add_u32 %0, %0, 1" : "+v"(ia));))
+PROBE(k_far256, REP64(asm volatile("s_branch 1f\n .fill 64, 4, 0xbf800000\n 1: v_add_u32 %0, %0, 1" : "+v"(ia));))
+PROBE(k_far1k, REP16(asm volatile("s_branch 1f\n .fill 256, 4, 0xbf800000\n 1: v_add_u32 %0, %0, 1" : "+v"(ia));))
+PROBE(k_far4k, REP4(asm volatile("s_branch 1f\n .fill 1024, 4, 0xbf800000\n 1: v_add_u32 %0, %0, 1" : "+v"(ia));))
+// backward and forward jumps between two places 2 KB apart (a loop with an out-of-line block)
+PROBE(k_pingpong, REP16(asm volatile("s_branch 2f\n 1: v_add_u32 %0, %0, 1\n s_branch 3f\n .fill 512, 4, 0xbf800000\n 2: v_add_u32 %0, %0, 2\n s_branch 1b\n 3:" : "+v"(ia));))
 PROBE(k_mixed, REP64(asm volatile("v_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1" : "+v"(ia), "+s"(sa) :: "scc");))
 __global__ void k_lds(unsigned long long *out, double *sink)
 {
@@ -73,7 +80,7 @@ template <class K> static void run(const char *name, K k, int n_inst, int waves_
 
 int main()
 {
-    for (int w : {4, 8}) {
+    for (int w : {4}) {
         run("empty(16 iters)", k_empty, 16, w);
         run("v_add_f32 dep", k_f32_dep, 16 * 64, w);
         run("v_add_f32 indep", k_f32_ind, 16 * 64, w);
@@ -88,6 +95,11 @@ int main()
         run("branch taken x2", k_branch_taken, 16 * 64, w);
         run("branch not taken", k_branch_nottaken, 16 * 64, w);
         run("execz skip block", k_execz_skip, 16 * 64, w);
+        run("taken, skip 64 B", k_far64, 16 * 64 * 2, w);
+        run("taken, skip 256 B", k_far256, 16 * 64 * 2, w);
+        run("taken, skip 1 KB", k_far1k, 16 * 16 * 2, w);
+        run("taken, skip 4 KB", k_far4k, 16 * 4 * 2, w);
+        run("out-of-line 2 KB x3", k_pingpong, 16 * 16 * 5, w);
         run("valu+salu mixed", k_mixed, 16 * 64 * 2, w);
         run("ds_read dep (+cvt)", k_lds, 256, w);
     }

@@ -3,7 +3,10 @@
 
 Needs the diagnostic library: `make -C alphazero_amd/csrc stamps`
 (libazmcts_stamps.so, 15x15 only).  Never used for throughput numbers: the
-stamps serialise the instruction stream.
+stamps serialise the instruction stream.  Phase boundaries are approximate: the
+compiler moves vector instructions across a stamp (the next root scan, for
+one, is scheduled above the loop-top stamp), so read the split together with
+the ISA.
 """
 import ctypes as C
 import os

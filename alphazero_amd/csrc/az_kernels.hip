@@ -506,28 +506,39 @@ __device__ __forceinline__ void prefetch_record(const char *rec, int lane, bool 
 
 // Hint for the next search: the runner-up of this root scan (the winner's own
 // visit lowers its score, the common sqrt factor moves all others alike).
-// Compared on the high word of the score only; a wrong hint costs nothing but
-// the prefetch.  Returns the runner-up's child link (0 = none) and visit count.
+// Ranked on the high word of the score only, with the low bits of that word
+// replaced by the action's position in its thread so that one integer maximum
+// yields both the value and whose it is; a wrong hint costs nothing but the
+// prefetch.  Every thread ranks its actions again without the winner (only the
+// winner's thread gets a new answer): branch-free.  Returns the runner-up's
+// child link (0 = none) and visit count.
 template <int E>
-__device__ __forceinline__ void runner_up(const NodeRegs<E> &R, const Cand &c, const double (&uk)[E], int win_a,
-                                          int tid, int &link2, int &n2)
+__device__ __forceinline__ void runner_up(const NodeRegs<E> &R, const double (&uk)[E], int win_a, int tid, int &link2,
+                                          int &n2)
 {
-    double v2 = c.u;
-    int l2 = c.link, m2 = c.n;
-    if (tid == win_a / E) { // the winner's thread offers its best remaining action
-        v2 = -INFINITY; l2 = 0; m2 = 0;
+    constexpr int KM = E <= 2 ? 1 : E <= 4 ? 3 : 7; // bits that hold the position
+    const int wk = tid == win_a / E ? win_a % E : -1;
+    int best = INT_MIN;
 #pragma unroll
-        for (int k = 0; k < E; k++) {
-            const bool gt = k != win_a % E && uk[k] > v2;
-            v2 = gt ? uk[k] : v2;
-            l2 = gt ? R.link[k] : l2;
-            m2 = gt ? R.n[k] : m2;
-        }
+    for (int k = 0; k < E; k++) {
+        const int hi = __double2hiint(uk[k]);
+        int key = hi ^ ((hi >> 31) & 0x7fffffff);  // integer order of the fp64 order
+        key = (key & ~KM) | (KM - k);              // earlier action wins a tie
+        key = k == wk ? INT_MIN : key;
+        best = key > best ? key : best;
     }
-    const int hi = __double2hiint(v2);
-    const int khi = hi ^ ((hi >> 31) & 0x7fffffff);
-    const int mhi = wave_max_i32(khi);
-    const unsigned long long mask = __ballot(khi == mhi);
+    const int j = KM - (best & KM);
+    int l2 = R.link[0], m2 = R.n[0];
+#pragma unroll
+    for (int k = 1; k < E; k++) {
+        l2 = j == k ? R.link[k] : l2;
+        m2 = j == k ? R.n[k] : m2;
+    }
+    // between threads the position bits must not count: equal scores go to the
+    // lowest lane, i.e. the lowest action
+    const int top = best & ~KM;
+    const int mx = wave_max_i32(top);
+    const unsigned long long mask = __ballot(top == mx);
     const int wl = __ffsll((long long)mask) - 1; // never empty: some lane holds the maximum
     link2 = lane_bcast_i32(l2, wl);
     n2 = lane_bcast_i32(m2, wl);
@@ -810,6 +821,9 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
     // v_readlane, not a dependent memory load on the critical path.
     int fs_batch = 0, fs_pos = 64;
     STAMP_DECL
+#ifdef AZ_PF_STATS
+    int pf_last = 0, pf_hit = 0, pf_total = 0;
+#endif
 
     double sq_root = sqrt_from_table(root_n, s_sqrt); // sqrt(nodeN + 1e-8) of the root, kept one search ahead
 
@@ -864,9 +878,13 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             scan_root<E>(R, C, sq_root, s.occ, tid, c, uk);
             pk = finish_pick<WPT, E>(c, tid, s_slots, phase);
             if constexpr (WPT == 1 && PREFETCH_NEXT)
-                if (AZ_LIKELY(pk.a >= 0)) runner_up<E>(R, c, uk, pk.a, tid, pf_link, pf_n);
+                if (AZ_LIKELY(pk.a >= 0)) runner_up<E>(R, uk, pk.a, tid, pf_link, pf_n);
         }
         STAMP(0);
+#ifdef AZ_PF_STATS
+        if (pk.link > 0) { pf_total++; if (pk.link == pf_last) pf_hit++; }
+        pf_last = pf_link;
+#endif
         if (AZ_UNLIKELY(pk.a < 0)) { err = AZ_ERR_NO_ACTION; break; }
         n_sel++;
         const int root_a = pk.a;
@@ -1019,6 +1037,9 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
         n_sims++;
         STAMP(6);
     }
+#ifdef AZ_PF_STATS
+    st_acc[5] = ((unsigned long long)pf_hit << 20) | pf_total;
+#endif
     STAMP_FLUSH(tree);
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): no prefetch may land in LDS after the group has ended
 

@@ -41,6 +41,11 @@ def main():
         xcc = (out[:, 6] >> np.uint64(40)).astype(np.int64)
         hw = (out[:, 7] >> np.uint64(40)).astype(np.int64)
         out &= np.uint64((1 << 40) - 1)
+        if os.environ.get("AZ_PF_STATS"):
+            hit = (out[:, 5] >> np.uint64(20)).sum()
+            tot = (out[:, 5] & np.uint64((1 << 20) - 1)).sum()
+            print(f"prefetch hint: {hit} of {tot} root picks with a child were the hinted record ({100.0 * hit / max(1, tot):.1f} %)")
+            out[:, 5] = 0
         per_tree = out.sum(axis=1)
         # placement: HW_ID = wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]
         simd_key = xcc * 65536 + (hw & 0xff30)

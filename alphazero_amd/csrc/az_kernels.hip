@@ -488,28 +488,12 @@ __device__ __forceinline__ void scan_root(const NodeRegs<E> &R, const RootCache<
     }
 }
 
-// Pulls the lines of a node record into L2 without touching a register: each
-// lane loads one dword of "its" 128-byte line straight into a scratch LDS word
-// (LDS-DMA load) that nobody reads.  A never-selected node only has its P section.
-__device__ __forceinline__ void prefetch_record(const char *rec, int lane, bool materialised, int *lds_sink)
-{
-    static_assert(REC_BYTES % 128 == 0 && OFF_P % 128 == 0, "record sections are line-aligned");
-    constexpr int LINES = REC_BYTES / 128, P_LINE = OFF_P / 128;
-#pragma unroll
-    for (int l0 = 0; l0 < LINES; l0 += 64) {
-        const int l = l0 + lane;
-        if (l < LINES && (materialised || l >= P_LINE))
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rec + (size_t)l * 128),
-                                             (__attribute__((address_space(3))) void *)lds_sink, 4, 0, 0);
-    }
-}
-
 // Hint for the next search: the runner-up of this root scan (the winner's own
 // visit lowers its score, the common sqrt factor moves all others alike).
 // Ranked on the high word of the score only, with the low bits of that word
 // replaced by the action's position in its thread so that one integer maximum
 // yields both the value and whose it is; a wrong hint costs nothing but the
-// prefetch.  Every thread ranks its actions again without the winner (only the
+// early load.  Every thread ranks its actions again without the winner (only the
 // winner's thread gets a new answer): branch-free.  Returns the runner-up's
 // child link (0 = none) and visit count.
 template <int E>
@@ -783,7 +767,6 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
     PathRegs path = {0, 0, 0, 0};
     __shared__ Slot s_slots[2 * WPT];
     __shared__ double s_sqrt[SQ_TAB];
-    __shared__ int s_sink[64]; // landing zone of the record prefetches, never read
     int phase = 0;
     for (int i = tid; i < SQ_TAB; i += T) s_sqrt[i] = __dsqrt_rn((double)i + 1e-8);
     __syncthreads();
@@ -860,6 +843,11 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): noise loads into the root registers are complete
         }
     }
+    // Child record of the likely next root pick, requested into registers of its own
+    // while the running search expands and backs up, so that the next search's first
+    // step below the root finds its node already loaded.
+    NodeRegs<E> nx;
+    int nx_link = 0; // LINK value of the record in flight into nx, 0 = none
     for (int i = first; i < A.n_total && err == 0; ++i) {
         if (AZ_UNLIKELY(worker_left == 0)) { // new worker, new generator (cmcts.cpp:132-133)
             noise_row = 0;
@@ -922,7 +910,10 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             const int nn = pk.n - 1;
             const bool fresh = nn == 0;
             NodeRegs<E> nd;
-            if (cur >= 0) load_node<E, false>(P, tree, cur, tid, fresh, nd);
+            // (links are unique per tree: an equal link is that very node, and what was
+            // loaded is current because no search has run since)
+            const bool piped = WPT == 1 && PREFETCH_NEXT && cur >= 0 && pk.link == nx_link;
+            if (cur >= 0 && !piped) load_node<E, false>(P, tree, cur, tid, fresh, nd);
             state_move<E>(s, pk.a, tid);
             STAMP(1);
             if (AZ_UNLIKELY(s.winner != -1.f)) { // cmcts.cpp:253-267: no node for a finished game
@@ -934,7 +925,15 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
                 __builtin_amdgcn_s_waitcnt(0x0F70);
                 STAMP(2);
 #endif
-                pk = select_pick<WPT, E>(nd, fresh, sqrt_from_table(nn, s_sqrt), s.occ, P.cpuct, tid, s_slots, phase);
+                if (piped) {
+                    // keeps the arithmetic on nx (and the wait for its loads) inside this branch
+#pragma unroll
+                    for (int k = 0; k < E; k++)
+                        asm volatile("" : "+v"(nx.n[k]), "+v"(nx.link[k]), "+v"(nx.w[k]), "+v"(nx.p[k]));
+                    pk = select_pick<WPT, E>(nx, fresh, sqrt_from_table(nn, s_sqrt), s.occ, P.cpuct, tid, s_slots, phase);
+                } else {
+                    pk = select_pick<WPT, E>(nd, fresh, sqrt_from_table(nn, s_sqrt), s.occ, P.cpuct, tid, s_slots, phase);
+                }
                 STAMP(3);
                 if (AZ_UNLIKELY(pk.a < 0)) {
                     leaf = NO_ACTION;
@@ -969,9 +968,10 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
         } while (leaf == GO);
 
         if constexpr (WPT == 1 && PREFETCH_NEXT) {
-            // fetched into L2 while this search expands and backs up, so the next
-            // search's child load does not pay the HBM latency
-            if (pf_link > 0) prefetch_record(rec_ptr(P, tree, pf_link - 1), tid, pf_n > 1, s_sink);
+            // requested now, after this search's last load (loads return in order: an
+            // earlier request would hold up the descent's own), used by the next search
+            if (pf_link > 0) load_node<E, false>(P, tree, pf_link - 1, tid, pf_n <= 1, nx);
+            nx_link = pf_link; // 0 = nothing requested: an older copy must never be reused
         }
         float value = 0.f;
         if (AZ_UNLIKELY(leaf == TERMINAL)) {
@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
     st_acc[5] = ((unsigned long long)pf_hit << 20) | pf_total;
 #endif
     STAMP_FLUSH(tree);
-    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): no prefetch may land in LDS after the group has ended
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the last search's early load is not left in flight
 
     if (root >= 0) store_stats<E>(P, tree, root, tid, R);
     if (tid == 0) {

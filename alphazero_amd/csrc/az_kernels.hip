@@ -1381,7 +1381,8 @@ __global__ __launch_bounds__(64) void k_get_counts(AzParams P, int *d_counts, in
 //   pi    = Cmcts::get_prob (mcts/src/cmcts.cpp:323-339): (float)((double)N/nodeN),
 //           prob_sum accumulated in index order, "Not a distribution" unless
 //           round(prob_sum*1000) == 1000;
-//   move  = pi.argmax() (first maximum) and pi := one-hot when `greedy`,
+//   move  = pi.argmax() (first maximum) and pi := one-hot when `greedy` (or when
+//           the tree's u is negative),
 //           else numpy.random.choice(SIZE, p=pi) for the uniform number u it is
 //           given: cdf = cumsum(p as fp64) in index order, cdf /= cdf[-1],
 //           move = number of cdf entries <= u (searchsorted, side='right');
@@ -1430,6 +1431,9 @@ __global__ __launch_bounds__(64) void k_choose_moves(AzParams P, const double *d
         if (lane == 0) { T->err = AZ_ERR_NOT_DIST; d_actions[tree] = -1; }
         return;
     }
+    // a negative uniform number asks for the greedy rule for this tree alone
+    // (games of one batch cross the sampling limit at different times)
+    if (!greedy && d_u[tree] < 0.) greedy = 1;
     int move;
     if (greedy) {
         float best = -INFINITY;

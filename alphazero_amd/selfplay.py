@@ -283,6 +283,123 @@ def self_play_games_device(batch0, batch1, sims, tau, init_moves=(), rng=None):
     return out
 
 
+def self_play_stream(batch0, batch1, sims, tau, n_games, init_moves=(), rng=None, flush_plies=32):
+    """`n_games` games of `self_play_game` (src/self_play.py:134-202) on the G tree
+    slots of the two batches, a finished game's slot being cleared and handed to
+    the next game instead of idling until the longest game of the batch is over
+    (game lengths spread over a factor of four, so a fixed batch leaves about
+    half of the evaluator's positions empty).
+
+    Every game follows the reference protocol on its own clock: pair index i of
+    the game decides sampling (i <= tau) or greedy, the first player's records
+    come first, labels as in src/self_play.py:194-200.  Slots stay in phase (the
+    first player of every live game moves on even half-steps), so a game that
+    ends on an even half-step leaves its slot empty for one half-step.  `rng`
+    supplies one uniform number per sampling game and half-step, in slot order.
+    Returns the list of per-game record arrays in game order."""
+    torch = batch0.torch
+    rng = np.random.default_rng() if rng is None else rng
+    G, S, size = batch0.n_trees, batch0.shape, batch0.size
+    assert batch1.n_trees == G and batch1.shape == S
+    dev = batch0.dev
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    dt = sample_dtype(S)
+    d_act = torch.empty(G, dtype=torch.int32, device=dev)
+    d_u = torch.zeros(G, dtype=torch.float64, device=dev)
+
+    game_of = np.full(G, -1, np.int64)   # game played in each slot, -1 = none
+    pair = np.zeros(G, np.int64)         # the game's pair index i (src/self_play.py:155)
+    alive = np.zeros(G, bool)
+    next_game = 0
+    rec_parts, key_parts = [], []        # flushed records and their (game, side, half-step) keys
+    outcome = np.full(n_games, -1.0, np.float32)
+    slabs = []  # (half-step, pi [G,SIZE] device, board [G,2,S,S] device, played bool[G], game_of copy)
+
+    def flush():
+        for step, pi, board, played, games in slabs:
+            idx = np.flatnonzero(played)
+            if idx.size == 0:
+                continue
+            sel = torch.from_numpy(idx).to(dev)
+            rec = np.zeros(idx.size, dt)
+            rec["pi"] = pi.index_select(0, sel).cpu().numpy()
+            rec["board"] = board.index_select(0, sel).cpu().numpy()
+            key = np.empty((idx.size, 3), np.int64)
+            key[:, 0], key[:, 1], key[:, 2] = games[idx], step & 1, step
+            rec_parts.append(rec)
+            key_parts.append(key)
+        slabs.clear()
+
+    def start_games():
+        nonlocal next_game
+        free = np.flatnonzero(~alive)
+        n_new = min(free.size, n_games - next_game)
+        if n_new == 0:
+            return
+        slots = free[:n_new]
+        mask = np.zeros(G, np.uint8)
+        mask[slots] = 1
+        batch0.eng.clear_masked(mask)  # Cmcts::clear (cmcts.cpp:23-28) for these slots
+        batch1.eng.clear_masked(mask)
+        for m in init_moves:
+            act = np.full(G, -1, np.int32)
+            act[slots] = m
+            batch0.make_move(act)
+            batch1.make_move(act)
+        game_of[slots] = np.arange(next_game, next_game + n_new)
+        pair[slots] = 0
+        alive[slots] = True
+        next_game += n_new
+
+    half = 0
+    while True:
+        side = half & 1
+        if side == 0:
+            start_games()
+        if not alive.any():
+            if next_game >= n_games:
+                break
+            half += 1  # every slot is waiting for the next even half-step
+            continue
+        searcher = batch0 if side == 0 else batch1
+        searcher.simulate(sims, alive)  # leaves exactly the live trees active
+        u = np.full(G, -1.0)            # negative = greedy for that tree
+        sampling = alive & (pair <= tau)
+        u[sampling] = rng.random(int(sampling.sum()))
+        d_u.copy_(torch.from_numpy(u))
+        pi = torch.empty((G, size), dtype=torch.float32, device=dev)
+        board = torch.empty((G, 2, S, S), dtype=torch.float32, device=dev)
+        searcher.eng.choose_moves(d_u.data_ptr(), False, d_act.data_ptr(), pi.data_ptr(), board.data_ptr(), stream)
+        slabs.append((half, pi, board, alive.copy(), game_of.copy()))
+        try:
+            batch0.eng.make_move_device(d_act.data_ptr(), stream)
+            batch1.eng.make_move_device(d_act.data_ptr(), stream)
+            searcher.eng.sync_check(stream)
+            winner = (batch1 if searcher is batch0 else batch0).eng.sync_states(stream)[2]
+        except _E.EngineError as e:
+            raise RuntimeError(str(e)) from None
+        done = alive & (winner != -1.0)
+        outcome[game_of[done]] = winner[done]
+        alive &= ~done
+        if side == 1:
+            pair[alive] += 1
+        if len(slabs) >= flush_plies:
+            flush()
+        half += 1
+    flush()
+    if not rec_parts:
+        return [np.zeros(0, dt) for _ in range(n_games)]
+    rec = np.concatenate(rec_parts)
+    key = np.concatenate(key_parts)
+    order = np.lexsort((key[:, 2], key[:, 1], key[:, 0]))  # by game, first player's records first, ply order
+    rec, key = rec[order], key[order]
+    won = outcome[key[:, 0]]
+    decided = (won == 0.0) | (won == 1.0)
+    rec["r"] = np.where(decided, np.where(won == key[:, 1], 1.0, -1.0), 1e-3).astype(np.float32)
+    bounds = np.searchsorted(key[:, 0], np.arange(n_games + 1))
+    return [rec[bounds[g]:bounds[g + 1]] for g in range(n_games)]
+
+
 def eval_games(best, latest, sims_best, sims_latest, init_moves=()):
     """`eval_models`' game loop (src/eval.py:111-149,187-209) for every game at once.
 

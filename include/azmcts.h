@@ -172,7 +172,10 @@ int az_select_greedy(az_engine *e, int *d_actions, void *stream);
  * d_actions [n_trees] receives the move (-1 for inactive trees), d_pi
  * [n_trees][SIZE] and d_board [n_trees][2][S][S] (either may be NULL) receive the
  * training record fields; rows of inactive trees are left untouched.  d_u may
- * be NULL when greedy.  The moves are NOT applied: pass d_actions to
+ * be NULL when greedy; with greedy == 0 a negative d_u[tree] selects the greedy
+ * rule for that tree alone (games of one batch pass the callers' sampling limit
+ * TAU at different times once finished games are replaced by new ones).  The
+ * moves are NOT applied: pass d_actions to
  * az_make_move(..., actions_on_device = 1, ...). */
 int az_choose_moves(az_engine *e, const double *d_u, int greedy, int *d_actions, float *d_pi, float *d_board,
                     void *stream);

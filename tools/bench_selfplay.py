@@ -29,7 +29,9 @@ def main():
     ap.add_argument("--tau", type=int, default=10)
     ap.add_argument("--eps", type=float, default=0.25)
     ap.add_argument("--mode", default="selfplay", choices=["selfplay", "arena"])
-    ap.add_argument("--max-plies", type=int, default=0, help="stop after this many plies (0 = play games out)")
+    ap.add_argument("--slots", type=int, default=0,
+                    help="self-play only: tree slots per GPU; finished games hand their slot to the next game "
+                         "(self_play_stream).  0 = one slot per game, all games in lock step")
     args = ap.parse_args()
     import torch
 
@@ -48,7 +50,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     lo, hi = sp.shard_range(args.games, rank, world)
-    G = hi - lo
+    n_mine = hi - lo
+    stream = args.mode == "selfplay" and 0 < args.slots < n_mine
+    G = args.slots if stream else n_mine
     nodes = args.sims * 3 + 64  # a move keeps at most the chosen child's subtree
     nets = []
     for seed in (0, 1):
@@ -59,16 +63,20 @@ def main():
     b1 = sp.TreeBatch(G, args.shape, nets[0 if args.mode == "selfplay" else 1], cpuct=4.0, eps=args.eps,
                       nodes_per_tree=nodes, device=local_rank, noise_seed=1000 + rank)
     size = args.shape * args.shape
-    opening = [np.array([(lo + g) % size for g in range(G)], np.int32)]  # distinct first stones
-    for act in opening:
-        b0.make_move(act)
-        b1.make_move(act)
+    if not stream:
+        opening = [np.array([(lo + g) % size for g in range(G)], np.int32)]  # distinct first stones
+        for act in opening:
+            b0.make_move(act)
+            b1.make_move(act)
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
     if args.mode == "selfplay":
-        games = sp.self_play_games_device(b0, b1, args.sims, args.tau, rng=np.random.default_rng(rank))
+        if stream:
+            games = sp.self_play_stream(b0, b1, args.sims, args.tau, n_mine, rng=np.random.default_rng(rank))
+        else:
+            games = sp.self_play_games_device(b0, b1, args.sims, args.tau, rng=np.random.default_rng(rank))
         local = np.concatenate(games) if games else np.zeros(0, sp.sample_dtype(args.shape))
         n_local = len(local)
         samples = sp.gather_samples(local)
@@ -85,7 +93,8 @@ def main():
     if rank == 0:
         out = {
             "workload": f"{args.mode}: {args.games} games of {args.shape}x{args.shape}, {args.sims} sims/move, "
-                        f"random-init reference net (fused f32 evaluator), eps={args.eps}, {world} GPU(s)",
+                        f"random-init reference net (fused f32 evaluator), eps={args.eps}, {world} GPU(s)"
+                        + (f", {G} slots per GPU refilled" if stream else ""),
             "wall_s": wall,
             "sims_per_s": counters[0] / wall,
             "games_per_s": args.games / wall,

@@ -130,6 +130,19 @@ def test_fused_800_sims_config2_sample():
     _play_fused(15, B=3, sims=800, plies=4, ev_kind="hash", eps=0.25, cpuct=4.0)
 
 
+@pytest.mark.timeout(400)
+def test_fused_config2_full_size_every_tree():
+    # the headline configuration at its full size: all 1024 trees x 800 sims/move, every
+    # tree's root (N, W, P, nodeN), states and the engine counters against the oracle
+    _play_fused(15, B=1024, sims=800, plies=6, ev_kind="uniform", eps=0.0, cpuct=4.0, nodes=4096)
+
+
+@pytest.mark.timeout(400)
+def test_fused_20x20_at_8192_trees():
+    # one GPU's share of the 20x20 configuration: 8192 concurrent trees, noise at every expansion
+    _play_fused(20, B=8192, sims=100, plies=3, ev_kind="hash", eps=0.25, cpuct=4.0, nodes=480)
+
+
 def test_fused_small_board_to_the_end():
     # 6x6 / 7x7 games run into terminals, draws and full boards inside the search
     for S in (6, 7):

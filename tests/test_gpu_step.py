@@ -152,3 +152,54 @@ def test_step_log_priors_tolerance():
     ot.simulate(1, O.callback_evaluator(lambda b, pl: (0.25, logp), S, log_priors=True))
     np.testing.assert_allclose(node[3], ot.root_p(), rtol=1e-6, atol=0)
     eng.close()
+
+
+@pytest.mark.timeout(400)
+def test_step_8192_trees_sampled_against_oracle():
+    """The network-driven configuration at its full width: 8192 concurrent trees on the
+    stepped path, one batched evaluator call per search step, noise at every
+    expansion; a spread of 48 trees is replayed by the oracle, invariants on all."""
+    from alphazero_amd import selfplay as sp
+    from helpers import ExactTorchEvaluator, oracle_exact_evaluator
+
+    G, S, sims, plies = 8192, 15, 100, 3
+    size = S * S
+    batch = sp.TreeBatch(G, S, ExactTorchEvaluator(), cpuct=4.0, eps=0.25, nodes_per_tree=sims * 3 + 64)
+    noise = np.random.default_rng(9).dirichlet(np.full(size, batch.eng.get_alpha()), size=sims + 4)
+    batch.set_noise_table(noise)
+    sample = sorted(set(int(x) for x in np.linspace(0, G - 1, 48)))
+    oev = oracle_exact_evaluator(S)
+    trees = {}
+    for g in sample:
+        t = O.OracleTree(S, cpuct=4.0)
+        t.set_alpha_default()
+        t.set_eps(0.25)
+        trees[g] = t
+    for ply in range(2):
+        act = np.array([O.opening(size, g)[ply] for g in range(G)], np.int32)
+        batch.make_move(act)
+        for g, t in trees.items():
+            t.make_move(int(act[g]))
+    carried = np.full(G, -1, np.int64)  # nodeN the root brought along, -1 = not expanded yet
+    for ply in range(plies):
+        batch.simulate(sims)
+        counts, root_n = batch.eng.get_counts()
+        # every tree: all searches but the one expanding a fresh root visit a child
+        assert np.array_equal(counts.sum(axis=1), root_n)
+        fresh = carried < 0
+        assert np.array_equal(root_n[fresh], np.full(int(fresh.sum()), sims - 1))
+        assert np.array_equal(root_n[~fresh], carried[~fresh] + sims)
+        for g, t in trees.items():
+            t.simulate(sims, oev, noise)
+            assert root_n[g] == t.root_n(), (ply, g)
+            assert np.array_equal(counts[g].astype(np.int64), t.root_counts()), (ply, g)
+        act = counts.argmax(axis=1).astype(np.int32)
+        # the chosen child's nodeN is its visit count minus the visit that created it
+        carried = counts[np.arange(G), act].astype(np.int64) - 1
+        batch.make_move(act)
+        for g, t in trees.items():
+            t.make_move(int(act[g]))
+        _, _, winner = batch.eng.get_states()
+        for g, t in trees.items():
+            assert float(winner[g]) == t.winner
+    batch.close()

@@ -160,7 +160,7 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
 // maximum itself.  The fp64 order is mapped to an integer order (high word
 // signed, low word unsigned, both flipped for negatives) so each butterfly step
 // is one 32-bit DPP max instead of moves plus a 64-bit max: first the high
-// words, then the low words among the lanes that tie on the high word.
+// words, then (if need be) the low words among the lanes that tie on the high word.
 // v + 0.0 folds -0.0 onto +0.0, which compare equal as doubles; no NaN enters.
 __device__ __forceinline__ unsigned long long wave_argmax_f64(double v, bool ok, double &m)
 {
@@ -170,10 +170,19 @@ __device__ __forceinline__ unsigned long long wave_argmax_f64(double v, bool ok,
     const int khi = hi ^ (sg & 0x7fffffff);
     const unsigned klo = (unsigned)(lo ^ sg);
     const int mhi = wave_max_i32(khi);
-    const unsigned mlo = wave_max_u32(khi == mhi ? klo : 0u);
+    // The lanes that tie on the high word nearly always share the low word too (a
+    // single lane, or scores that are equal bit for bit): then they all hold the
+    // maximum and the second reduction is skipped.
+    const unsigned long long thi = __ballot(khi == mhi); // never empty
+    unsigned mlo = (unsigned)lane_bcast_i32((int)klo, __ffsll((long long)thi) - 1);
+    unsigned long long top = thi;
+    if (AZ_UNLIKELY((thi & ~__ballot(klo == mlo)) != 0ull)) {
+        mlo = wave_max_u32(khi == mhi ? klo : 0u);
+        top = __ballot(khi == mhi && klo == mlo);
+    }
     const int msg = mhi >> 31;
     m = __hiloint2double(mhi ^ (msg & 0x7fffffff), (int)mlo ^ msg);
-    return __ballot(ok && khi == mhi && klo == mlo);
+    return top & __ballot(ok);
 }
 
 // node arena of one tree (wave-uniform) and a record's byte offset inside it

@@ -8,7 +8,8 @@
 // buffers with a zero halo), so HBM sees only the input planes and the outputs.
 // Every 3x3 convolution is an implicit GEMM on the f32-input matrix cores
 // (v_mfma_f32_16x16x4_f32: exact f32 products, f32 accumulate): M = 16 pixels of
-// one board row, N = the 16 output channels, K = 4 input channels of one tap;
+// one board row (boards wider than 16: 16 consecutive pixels in row-major order,
+// see Geo::FLAT), N = the 16 output channels, K = 4 input channels of one tap;
 // each wavefront carries four independent accumulators (four rows), which is
 // what the 40-cycle dependent latency of that instruction needs.  The 1-channel
 // heads run on the VALU.
@@ -28,7 +29,14 @@ template <int S> struct Geo {
     static constexpr int ROW = S + 2;               // one halo column on each side
     static constexpr int PLANE = ROW * ROW;
     static constexpr int TPR = (S + 15) / 16;       // 16-pixel tiles per board row
-    static constexpr int NT = S * TPR;              // tiles per plane
+    // Tiles of one row each keep every operand read inside a row (fewer LDS bank
+    // conflicts: 16 % faster at 15x15), but a row of 17..20 pixels needs two tiles,
+    // the second nearly empty.  There the tiles run over the board in row-major
+    // order instead and cross row ends (25 instead of 40 tiles at 20x20, two rounds
+    // of the four wavefronts instead of three: 19 % faster).
+    static constexpr int NT_ROW = S * TPR, NT_FLAT = (SIZE + 15) / 16;
+    static constexpr bool FLAT = (NT_FLAT + 15) / 16 < (NT_ROW + 15) / 16;
+    static constexpr int NT = FLAT ? NT_FLAT : NT_ROW; // tiles per plane
     // plane stride: room for the over-reads of the padded tile lanes, and odd (= 1
     // mod 32) so the epilogue's writes, whose lanes step by one PLANE per output
     // channel, spread over all LDS banks (measured 5 % faster than = 16 mod 32,
@@ -74,9 +82,15 @@ __device__ __forceinline__ void conv3x3(const float *in, float *out, const Layer
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int tile = tile0 + t < G::NT ? tile0 + t : G::NT - 1;
-            const int y = tile / G::TPR, x = (tile % G::TPR) * 16 + (lane & 15);
-            base[t] = (y + 1) * G::ROW + x + 1;
+            if constexpr (G::FLAT) {
+                int p = (tile0 + t) * 16 + (lane & 15);
+                p = p < G::SIZE ? p : G::SIZE - 1; // lanes past the board compute a pixel nobody stores
+                base[t] = (p / S + 1) * G::ROW + p % S + 1;
+            } else {
+                const int tile = tile0 + t < G::NT ? tile0 + t : G::NT - 1;
+                const int y = tile / G::TPR, x = (tile % G::TPR) * 16 + (lane & 15);
+                base[t] = (y + 1) * G::ROW + x + 1;
+            }
         }
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ks++) {
@@ -91,7 +105,17 @@ __device__ __forceinline__ void conv3x3(const float *in, float *out, const Layer
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int tile = tile0 + t;
-            if (tile < G::NT) {
+            if constexpr (G::FLAT) {
+                // accumulator register r of this lane: pixel tile*16 + kq*4 + r, channel co
+                const int p0 = tile * 16 + kq * 4;
+                int y = p0 / S, x = p0 % S;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (p0 + r < G::SIZE)
+                        out[co * G::PS + (y + 1) * G::ROW + x + 1] = fmaxf(acc[t][r] * w.sc + w.sh, 0.f);
+                    if (++x == S) { x = 0; y++; }
+                }
+            } else if (tile < G::NT) {
                 const int y = tile / G::TPR, x0 = (tile % G::TPR) * 16 + kq * 4;
 #pragma unroll
                 for (int r = 0; r < 4; r++)

@@ -162,7 +162,7 @@ __device__ __forceinline__ void policy_head(const float *src, const float *p_pol
 }
 
 template <int S>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_eval(const float *boards, int n, const float *prm, int front, int pol,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_eval(const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol,
                                                   int val, float *value_out, float *logp_out)
 {
     using G = Geo<S>;
@@ -170,6 +170,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float *A = lds, *B = lds + CH * G::PS, *C = lds + 2 * CH * G::PS;
     float *red = lds + 3 * CH * G::PS; // [8] reduction scratch + logits [SIZE]
     float *logit = red + 8;
+    int *todo = reinterpret_cast<int *>(logit + G::SIZE); // [ceil(n / gridDim.x)] positions of this workgroup
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int i = tid; i < 3 * CH * G::PS; i += 256) lds[i] = 0.f; // halos stay zero from here on
     __syncthreads();
@@ -185,7 +186,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     LayerRegs<5> w0;
     load_layer<5>(prm, lane, w0);
 
-    for (int pos = blockIdx.x; pos < n; pos += gridDim.x) {
+    // Positions to evaluate: every gridDim.x-th one, counted among those that need an
+    // evaluation (a search that ended on a finished game, or an idle tree, needs
+    // none), so the workgroups stay balanced however the skipped ones are spread.
+    // Every workgroup derives its list from the codes by itself: no atomics, no
+    // second kernel.
+    int n_mine;
+    if (leaf_kind != nullptr) {
+        int *cnt = reinterpret_cast<int *>(red); // [4] per-wavefront totals (scratch is free before the first head)
+        const int per = (n + 255) / 256, lo = tid * per, hi = lo + per < n ? lo + per : n;
+        int c = 0;
+        for (int i = lo; i < hi; i++) c += leaf_kind[i] == AZ_LEAF_EXPAND;
+        int incl = c; // inclusive prefix over the wavefront, then over the four wavefronts
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) cnt[wave] = incl;
+        __syncthreads();
+        int before = incl - c, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if (w < wave) before += cnt[w];
+            total += cnt[w];
+        }
+        for (int i = lo; i < hi; i++)
+            if (leaf_kind[i] == AZ_LEAF_EXPAND) {
+                if (before % (int)gridDim.x == (int)blockIdx.x) todo[before / (int)gridDim.x] = i;
+                before++;
+            }
+        n_mine = total > (int)blockIdx.x ? (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+        __syncthreads();
+    } else {
+        n_mine = n > (int)blockIdx.x ? (n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    }
+    for (int it = 0; it < n_mine; it++) {
+        const int pos = leaf_kind != nullptr ? todo[it] : (int)blockIdx.x + it * (int)gridDim.x;
         // raw planes into channels 0..1 of A (channels 2..15 of A may hold stale
         // interior values of the previous position: the 2-plane layer never reads them)
         for (int i = tid; i < CIN * G::SIZE; i += 256) {
@@ -238,24 +275,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-template <int S> int launch(const float *boards, int n, const float *prm, int front, int pol, int val, float *value_out,
+template <int S> int launch(const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val, float *value_out,
                             float *logp_out, hipStream_t st)
 {
     using G = Geo<S>;
-    const size_t lds_bytes = (size_t)(3 * CH * G::PS + 8 + G::SIZE) * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
+    const size_t fixed_bytes = (size_t)(3 * CH * G::PS + 8 + G::SIZE) * sizeof(float);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int per_cu = (int)(160 * 1024 / fixed_bytes) > 0 ? (int)(160 * 1024 / fixed_bytes) : 1;
+    int grid = cus * per_cu;
+    if (grid > n) grid = n;
+    // + the workgroup's own list of positions (at most ceil(n / grid) entries)
+    const size_t lds_bytes = fixed_bytes + (size_t)((n + grid - 1) / grid) * sizeof(int);
+    static size_t configured = 0; // largest size the kernel has been opened up to
+    if (lds_bytes > configured) {
         if (hipFuncSetAttribute((const void *)k_net_eval<S>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes) != hipSuccess)
             return AZ_ERR_HIP;
-        configured = true;
+        configured = lds_bytes;
     }
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int per_cu = (int)(160 * 1024 / lds_bytes) > 0 ? (int)(160 * 1024 / lds_bytes) : 1;
-    int grid = cus * per_cu;
-    if (grid > n) grid = n;
-    hipLaunchKernelGGL(k_net_eval<S>, dim3(grid), dim3(256), lds_bytes, st, boards, n, prm, front, pol, val, value_out,
+    hipLaunchKernelGGL(k_net_eval<S>, dim3(grid), dim3(256), lds_bytes, st, boards, leaf_kind, n, prm, front, pol, val, value_out,
                        logp_out);
     return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
 }
@@ -270,8 +309,8 @@ int az_net_param_floats(int front_layers, int policy_layers, int value_layers)
     return FIRST_FLOATS + (front_layers - 1 + policy_layers + value_layers) * LAYER_FLOATS + POLICY_FLOATS + VALUE_FLOATS;
 }
 
-int az_net_eval(int shape, int n, const float *d_boards, const float *d_params, int front_layers, int policy_layers,
-                int value_layers, float *d_value, float *d_logp, void *stream)
+int az_net_eval(int shape, int n, const float *d_boards, const int *d_leaf_kind, const float *d_params,
+                int front_layers, int policy_layers, int value_layers, float *d_value, float *d_logp, void *stream)
 {
     if (n < 0 || front_layers < 1 || policy_layers < 0 || value_layers < 0) return AZ_ERR_ARG;
     if (n == 0) return AZ_OK;
@@ -279,7 +318,7 @@ int az_net_eval(int shape, int n, const float *d_boards, const float *d_params, 
     hipStream_t st = (hipStream_t)stream;
     switch (shape) {
 #define AZ_NET_CASE(s) \
-    case s: return launch<s>(d_boards, n, d_params, front_layers, policy_layers, value_layers, d_value, d_logp, st);
+    case s: return launch<s>(d_boards, d_leaf_kind, n, d_params, front_layers, policy_layers, value_layers, d_value, d_logp, st);
         AZ_NET_CASE(5) AZ_NET_CASE(6) AZ_NET_CASE(7) AZ_NET_CASE(8) AZ_NET_CASE(9) AZ_NET_CASE(10) AZ_NET_CASE(11)
         AZ_NET_CASE(12) AZ_NET_CASE(13) AZ_NET_CASE(14) AZ_NET_CASE(15) AZ_NET_CASE(16) AZ_NET_CASE(17)
         AZ_NET_CASE(18) AZ_NET_CASE(19) AZ_NET_CASE(20)

@@ -136,12 +136,17 @@ class FusedNetEvaluator:
         out += [wv.reshape(-1), state["value.0.bias"].detach().double().cpu().reshape(-1)]
         return torch.cat(out).to(torch.float32).contiguous(), (front, pol, val)
 
-    def __call__(self, boards):
+    takes_leaf_kinds = True
+
+    def __call__(self, boards, leaf_kinds=None):
+        """leaf_kinds: the int32 codes az_select wrote for this step (device tensor);
+        boards that need no evaluation are skipped, their outputs are undefined."""
         n, size = boards.shape[0], self.shape * self.shape
         boards = boards.contiguous()
         value = torch.empty(n, dtype=torch.float32, device=boards.device)
         logp = torch.empty((n, size), dtype=torch.float32, device=boards.device)
-        rc = self.L.az_net_eval(self.shape, n, boards.data_ptr(), self.params.data_ptr(), *self.layers,
+        rc = self.L.az_net_eval(self.shape, n, boards.data_ptr(),
+                                None if leaf_kinds is None else leaf_kinds.data_ptr(), self.params.data_ptr(), *self.layers,
                                 value.data_ptr(), logp.data_ptr(), torch.cuda.current_stream(boards.device).cuda_stream)
         if rc != 0:
             raise RuntimeError(f"az_net_eval failed (code {rc})")

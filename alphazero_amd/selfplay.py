@@ -85,7 +85,10 @@ class TreeBatch:
                 eng.begin_simulate(stream)
                 for _ in range(per):
                     eng.select(self.boards.data_ptr(), self.kinds.data_ptr(), stream)
-                    value, prior = self.evaluator(self.boards)
+                    if getattr(self.evaluator, "takes_leaf_kinds", False):
+                        value, prior = self.evaluator(self.boards, self.kinds)  # idle / terminal leaves skipped
+                    else:
+                        value, prior = self.evaluator(self.boards)
                     eng.expand_backup(value.data_ptr(), prior.data_ptr(), self.evaluator.log_priors, stream)
         try:
             eng.sync_check(stream)

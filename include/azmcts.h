@@ -256,13 +256,17 @@ int az_aug_unique_average(int shape, int n_unique, const int *d_members, const i
  * (mcts/src/cmcts.cpp:206-231); this evaluates all n leaf boards of a search
  * step in one launch.  d_boards: float32 [n][2][S][S] raw planes (what az_select
  * writes); outputs d_value [n] and d_logp [n][S*S] (log-softmax, so
- * az_expand_backup takes them with prior_is_log = 1).  d_params: the network's
+ * az_expand_backup takes them with prior_is_log = 1).  d_leaf_kind (may be
+ * NULL): the step's AZ_LEAF_* codes as az_select wrote them; boards whose code
+ * is not AZ_LEAF_EXPAND are skipped and their outputs left untouched
+ * (az_expand_backup does not read them: the reference, too, calls its network
+ * only when it expands, cmcts.cpp:190-231).  d_params: the network's
  * inference parameters packed by the host (alphazero_amd/evaluator.py,
  * FusedNetEvaluator.pack): az_net_param_floats(...) floats; 2 input planes and
  * 16 conv channels (config.py:12-15), layer counts as given. */
 int az_net_param_floats(int front_layers, int policy_layers, int value_layers);
-int az_net_eval(int shape, int n, const float *d_boards, const float *d_params, int front_layers, int policy_layers,
-                int value_layers, float *d_value, float *d_logp, void *stream);
+int az_net_eval(int shape, int n, const float *d_boards, const int *d_leaf_kind, const float *d_params,
+                int front_layers, int policy_layers, int value_layers, float *d_value, float *d_logp, void *stream);
 
 #ifdef __cplusplus
 }

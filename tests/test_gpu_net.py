@@ -93,3 +93,29 @@ def test_torchscript_file_of_the_reference_architecture_gets_the_fused_kernel(tm
     path2 = str(tmp_path / "other.pt")
     torch.jit.trace(other, torch.rand(1, 2, S, S)).save(path2)
     assert isinstance(load_evaluator(path2, S), TorchEvaluator)
+
+
+def test_fused_net_skips_leaves_that_need_no_evaluation():
+    """az_net_eval with the step's leaf codes: boards coded AZ_LEAF_EXPAND get the
+    same outputs as without the codes, all other rows stay untouched."""
+    import torch
+    from alphazero_amd.evaluator import FusedNetEvaluator
+
+    shape, n = 15, 700
+    size = shape * shape
+    ev = FusedNetEvaluator(_model(shape, 4, 2, 2, 8).float(), shape)
+    boards = torch.from_numpy(_boards(n, shape, 2)).cuda()
+    v_all, lp_all = ev(boards)
+    kinds = torch.from_numpy(np.random.default_rng(4).integers(0, 3, n).astype(np.int32)).cuda()  # NONE / EXPAND / TERMINAL
+    value = torch.full((n,), 7.0, dtype=torch.float32, device="cuda")
+    logp = torch.full((n, size), 7.0, dtype=torch.float32, device="cuda")
+    rc = ev.L.az_net_eval(shape, n, boards.data_ptr(), kinds.data_ptr(), ev.params.data_ptr(), *ev.layers,
+                          value.data_ptr(), logp.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    need = (kinds == 1).cpu().numpy()
+    assert 0 < need.sum() < n
+    value, logp = value.cpu().numpy(), logp.cpu().numpy()
+    assert np.array_equal(value[need], v_all.cpu().numpy()[need])
+    assert np.array_equal(logp[need], lp_all.cpu().numpy()[need])
+    assert np.all(value[~need] == 7.0) and np.all(logp[~need] == 7.0)

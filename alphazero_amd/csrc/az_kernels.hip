@@ -886,19 +886,21 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
         n_sel++;
         const int root_a = pk.a;
         const bool root_owner = tid == root_a / E;
-        // the visit and the virtual loss (node.cpp:116-118) of the picked action,
-        // as additions of 0 or 1 (x + 0.0 and x - 0.0 are x for these values)
+        // the visit and the virtual loss (node.cpp:116-118) of the picked action, as
+        // unconditional additions of 0 or 1 to all of a thread's actions (x + 0.0 and
+        // x - 0.0 are x for these values): two selects and three additions per
+        // action, no branch and no select of the results
         {
-            const int root_k = root_a % E; // wave-uniform: only the matching registers are touched
-            const double one = root_owner ? 1. : 0.;
-            const int onei = root_owner ? 1 : 0;
+            const int root_k = root_a % E;
 #pragma unroll
-            for (int k = 0; k < E; k++)
-                if (root_k == k) {
-                    R.n[k] += onei;
-                    C.np1[k] += one;
-                    R.w[k] -= one;
-                }
+            for (int k = 0; k < E; k++) {
+                const bool hit = root_owner && root_k == k;
+                const int onei = hit ? 1 : 0;
+                const double one = hit ? 1. : 0.;
+                R.n[k] += onei;
+                C.np1[k] += one;
+                R.w[k] -= one;
+            }
         }
         root_n += 1;
         sq_root = sqrt_from_table(root_n, s_sqrt); // for the next search: the table read overlaps this one

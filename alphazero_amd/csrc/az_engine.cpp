@@ -69,6 +69,7 @@ struct az_engine {
     int noise_cap = 0;             // rows allocated at d_noise
     std::vector<AzTree> h_trees;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> ev_slots; // [2 * slot + end] for az_timing_mark, created on first use
 };
 
 namespace {
@@ -86,6 +87,21 @@ struct DeviceGuard {
         if (prev >= 0) (void)hipSetDevice(prev);
     }
 };
+
+// trees whose game is over (State::winner != -1, state.cpp:95-103) -> mask, + their number
+__global__ void k_mark_finished(const AzTree *trees, int n, unsigned char *mask, int *count)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const bool over = trees[t].winner != -1.f;
+    mask[t] = over ? 1 : 0;
+    if (over && count != nullptr) atomicAdd(count, 1);
+}
+__global__ void k_masked_actions(const unsigned char *mask, const int *src, int n, int *actions)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) actions[t] = mask[t] ? src[t] : -1;
+}
 
 template <typename T> int dev_alloc(az_engine *e, T **p, size_t count)
 {
@@ -232,6 +248,8 @@ void az_destroy(az_engine *e)
         if (p) (void)hipFree(p);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
+    for (hipEvent_t ev : e->ev_slots)
+        if (ev) (void)hipEventDestroy(ev);
     delete e;
 }
 
@@ -334,6 +352,23 @@ int az_clear_masked(az_engine *e, const unsigned char *mask)
         if (e->ops->clear(e->P, nullptr, nullptr)) return fail(AZ_ERR_HIP, "clear launch failed");
     }
     HIP_TRY(hipDeviceSynchronize());
+    return AZ_OK;
+}
+
+int az_restart_finished(az_engine *e, const int *d_openings, int n_plies, int *d_count, void *stream)
+{
+    if (!e || n_plies < 0 || (n_plies > 0 && !d_openings)) return fail(AZ_ERR_ARG, "bad argument");
+    DeviceGuard g(e->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int n = e->n_trees, blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_mark_finished, dim3(blocks), dim3(256), 0, st, e->P.trees, n, e->d_mask, d_count);
+    if (e->ops->clear(e->P, e->d_mask, stream)) return fail(AZ_ERR_HIP, "clear launch failed");
+    for (int ply = 0; ply < n_plies; ply++) {
+        hipLaunchKernelGGL(k_masked_actions, dim3(blocks), dim3(256), 0, st, e->d_mask, d_openings + (size_t)ply * n, n,
+                           e->d_actions);
+        if (e->ops->make_move(e->P, e->d_actions, stream)) return fail(AZ_ERR_HIP, "make_move launch failed");
+    }
+    if (hipGetLastError() != hipSuccess) return fail(AZ_ERR_HIP, "restart launch failed");
     return AZ_OK;
 }
 
@@ -775,6 +810,29 @@ int az_timing_end(az_engine *e, void *stream, float *ms)
     HIP_TRY(hipEventRecord(e->ev1, (hipStream_t)stream));
     HIP_TRY(hipEventSynchronize(e->ev1));
     HIP_TRY(hipEventElapsedTime(ms, e->ev0, e->ev1));
+    return AZ_OK;
+}
+
+int az_timing_mark(az_engine *e, int slot, int end, void *stream)
+{
+    if (!e || slot < 0 || slot >= 65536) return fail(AZ_ERR_ARG, "bad timing slot");
+    DeviceGuard g(e->device);
+    const size_t idx = 2 * (size_t)slot + (end ? 1 : 0);
+    if (e->ev_slots.size() <= idx) e->ev_slots.resize(2 * (size_t)slot + 2, nullptr);
+    if (!e->ev_slots[idx]) HIP_TRY(hipEventCreate(&e->ev_slots[idx]));
+    HIP_TRY(hipEventRecord(e->ev_slots[idx], (hipStream_t)stream));
+    return AZ_OK;
+}
+
+int az_timing_elapsed(az_engine *e, int slot, float *ms)
+{
+    if (!e || !ms || slot < 0) return fail(AZ_ERR_ARG, "bad argument");
+    const size_t idx = 2 * (size_t)slot;
+    if (e->ev_slots.size() < idx + 2 || !e->ev_slots[idx] || !e->ev_slots[idx + 1])
+        return fail(AZ_ERR_ARG, "timing slot was not marked at both ends");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipEventSynchronize(e->ev_slots[idx + 1]));
+    HIP_TRY(hipEventElapsedTime(ms, e->ev_slots[idx], e->ev_slots[idx + 1]));
     return AZ_OK;
 }
 

@@ -76,6 +76,9 @@ SYMBOLS = [
     ("az_get_pool_usage", _i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
     ("az_sync_check", _i, [_vp, _vp]),
     ("az_sync_states", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("az_restart_finished", _i, [_vp, _vp, _i, _vp, _vp]),
+    ("az_timing_mark", _i, [_vp, _i, _i, _vp]),
+    ("az_timing_elapsed", _i, [_vp, _i, C.POINTER(_f)]),
     ("az_timing_begin", _i, [_vp, _vp]),
     ("az_timing_end", _i, [_vp, _vp, C.POINTER(_f)]),
 ]
@@ -318,6 +321,19 @@ class Engine:
         u, m = C.c_int(), C.c_int()
         self._check(self.L.az_get_pool_usage(self.h, tree, C.byref(u), C.byref(m)))
         return u.value, m.value
+
+    def restart_finished(self, d_openings, n_plies, d_count=None, stream=None):
+        """clear + opening moves for every finished game, on the GPU (device pointers)."""
+        self._check(self.L.az_restart_finished(self.h, _ptr(d_openings) if n_plies else None, int(n_plies),
+                                               _ptr(d_count) if d_count is not None else None, stream))
+
+    def timing_mark(self, slot, end, stream=None):
+        self._check(self.L.az_timing_mark(self.h, int(slot), int(bool(end)), stream))
+
+    def timing_elapsed(self, slot):
+        ms = _f()
+        self._check(self.L.az_timing_elapsed(self.h, int(slot), C.byref(ms)))
+        return ms.value
 
     def timing_begin(self, stream=None): self._check(self.L.az_timing_begin(self.h, stream))
 

@@ -123,22 +123,23 @@ def main():
 
     open_games()
     d_actions = torch.empty(B, dtype=torch.int32, device=dev)
-    kernel_ms = []
+    d_openings = torch.from_numpy(op).to(dev)                      # [2][B]
+    d_restarts = torch.zeros(1, dtype=torch.int32, device=dev)
+    timed_slots = []
 
     def step(timed):
+        # everything stays on the stream: no host round trip inside a step (finished
+        # games are cleared and re-opened by az_restart_finished, the kernel's HIP
+        # events are read after the timed region)
         if timed:
-            eng.timing_begin(stream)
+            eng.timing_mark(len(timed_slots), 0, stream)
         eng.simulate_fused(SIMS, E.EVAL_UNIFORM, prior, 0.0, 0, stream, sync=False)
         if timed:
-            kernel_ms.append(eng.timing_end(stream))
+            eng.timing_mark(len(timed_slots), 1, stream)
+            timed_slots.append(len(timed_slots))
         eng.select_greedy(d_actions.data_ptr(), stream)
         eng.make_move_device(d_actions.data_ptr(), stream)
-        _, _, winner = eng.sync_states(stream)
-        fin = winner != -1.0
-        if fin.any():
-            eng.clear_masked(fin.astype(np.uint8))
-            open_games(fin)
-        return int(fin.sum())
+        eng.restart_finished(d_openings.data_ptr(), 2, d_restarts.data_ptr(), stream)
 
     def barrier():
         if dist is not None:
@@ -147,14 +148,18 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+    eng.sync_check(stream)
     eng.reset_stats()
+    d_restarts.zero_()
     barrier()
     t0 = time.perf_counter()
-    restarts = 0
     for _ in range(args.steps):
-        restarts += step(True)
+        step(True)
     barrier()
     elapsed = time.perf_counter() - t0
+    eng.sync_check(stream)  # a tree in error would have stopped searching: fail loudly
+    kernel_ms = [eng.timing_elapsed(i) for i in timed_slots]
+    restarts = int(d_restarts.item())
 
     st = eng.get_stats()
     used, max_used = eng.pool_usage(0)

@@ -100,6 +100,13 @@ int az_get_states(az_engine *e, int *player, int *move_cnt, float *winner);
 int az_clear(az_engine *e, int tree);
 /* clear the trees whose mask byte is non-zero (host array of n_trees) */
 int az_clear_masked(az_engine *e, const unsigned char *mask);
+/* What a game loop does with a finished game (src/self_play.py:86-91: mcts.clear()
+ * then tools.make_init_moves, src/tools.py:41-44) for every tree whose game is
+ * over, without a host round trip: Cmcts::clear, then the moves
+ * d_openings[ply][tree] (device int32 [n_plies][n_trees]) for ply = 0..n_plies-1.
+ * *d_count (device int, may be NULL) is increased by the number of such trees.
+ * Asynchronous on `stream`; errors surface at az_sync_check. */
+int az_restart_finished(az_engine *e, const int *d_openings, int n_plies, int *d_count, void *stream);
 
 /* which trees take part in simulate / select (host array of n_trees bytes;
  * NULL = all).  Trees left out keep their state untouched. */
@@ -226,6 +233,11 @@ int az_sync_states(az_engine *e, void *stream, int *player, int *move_cnt, float
  * returns elapsed milliseconds. */
 int az_timing_begin(az_engine *e, void *stream);
 int az_timing_end(az_engine *e, void *stream, float *ms);
+/* The same without a wait inside a loop: az_timing_mark records the start
+ * (end = 0) or end (end = 1) event of `slot`, az_timing_elapsed waits for the
+ * slot's end event and returns the time between the two. */
+int az_timing_mark(az_engine *e, int slot, int end, void *stream);
+int az_timing_elapsed(az_engine *e, int slot, float *ms);
 
 /* ---- trainer-side sample preparation (src/tools.py:46-88), no engine needed.
  * Samples are the record fields of src/self_play.py:153 as dense device arrays:

@@ -231,3 +231,45 @@ def test_clear_and_reuse():
     c2, n2 = eng.get_counts()
     assert np.array_equal(c1, c2) and np.array_equal(n1, n2)
     eng.close()
+
+
+def test_restart_finished_on_device_equals_host_clear_and_openings():
+    """az_restart_finished (clear + opening moves of finished games without a host
+    round trip) against az_clear_masked + az_make_move from the host on a twin engine."""
+    import torch
+    from alphazero_amd import engine as E
+
+    S, B, sims = 6, 24, 40
+    size = S * S
+    op = np.array([[O.opening(size, g)[ply] for g in range(B)] for ply in range(2)], np.int32)
+    engines = [E.Engine(B, S, nodes_per_tree=2000, cpuct=2.0) for _ in range(2)]
+    for eng in engines:
+        eng.set_eps(0.0)
+        for ply in range(2):
+            eng.make_move(op[ply])
+    d_open = torch.from_numpy(op).cuda()
+    d_count = torch.zeros(1, dtype=torch.int32, device="cuda")
+    restarted = 0
+    for ply in range(3 * size):
+        states = []
+        for k, eng in enumerate(engines):
+            eng.simulate_fused(sims, eval_kind=E.EVAL_HASH, hash_seed=21)
+            counts, root_n = eng.get_counts()
+            eng.make_move(counts.argmax(axis=1).astype(np.int32))
+            if k == 0:
+                eng.restart_finished(d_open.data_ptr(), 2, d_count.data_ptr())
+                eng.sync_check()
+            else:
+                fin = eng.get_states()[2] != -1.0
+                restarted += int(fin.sum())
+                if fin.any():
+                    eng.clear_masked(fin.astype(np.uint8))
+                    for p in range(2):
+                        eng.make_move(np.where(fin, op[p], -1).astype(np.int32))
+            states.append((counts, root_n) + tuple(eng.get_states()))
+        for a, b in zip(*states):
+            assert np.array_equal(a, b), ply
+    assert restarted > B  # every slot has seen more than one game
+    assert int(d_count.item()) == restarted
+    for eng in engines:
+        eng.close()

@@ -97,6 +97,7 @@ struct AzShapeOps {
     int (*choose_moves)(const AzParams &, const double *d_u, int greedy, int *d_actions, float *d_pi,
                         float *d_board, void *stream);
     int (*dirichlet)(double *d_table, int rows, double alpha, unsigned long long seed, void *stream);
+    int (*restart)(const AzParams &, const int *d_openings, int n_plies, int *d_count, void *stream);
 };
 
 #endif

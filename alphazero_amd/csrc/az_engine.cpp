@@ -88,21 +88,6 @@ struct DeviceGuard {
     }
 };
 
-// trees whose game is over (State::winner != -1, state.cpp:95-103) -> mask, + their number
-__global__ void k_mark_finished(const AzTree *trees, int n, unsigned char *mask, int *count)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const bool over = trees[t].winner != -1.f;
-    mask[t] = over ? 1 : 0;
-    if (over && count != nullptr) atomicAdd(count, 1);
-}
-__global__ void k_masked_actions(const unsigned char *mask, const int *src, int n, int *actions)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) actions[t] = mask[t] ? src[t] : -1;
-}
-
 template <typename T> int dev_alloc(az_engine *e, T **p, size_t count)
 {
     size_t bytes = count * sizeof(T);
@@ -355,20 +340,19 @@ int az_clear_masked(az_engine *e, const unsigned char *mask)
     return AZ_OK;
 }
 
+int az_make_move_greedy(az_engine *e, void *stream)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    DeviceGuard g(e->device);
+    if (e->ops->make_move(e->P, nullptr, stream)) return fail(AZ_ERR_HIP, "make_move launch failed");
+    return AZ_OK;
+}
+
 int az_restart_finished(az_engine *e, const int *d_openings, int n_plies, int *d_count, void *stream)
 {
     if (!e || n_plies < 0 || (n_plies > 0 && !d_openings)) return fail(AZ_ERR_ARG, "bad argument");
     DeviceGuard g(e->device);
-    hipStream_t st = (hipStream_t)stream;
-    const int n = e->n_trees, blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(k_mark_finished, dim3(blocks), dim3(256), 0, st, e->P.trees, n, e->d_mask, d_count);
-    if (e->ops->clear(e->P, e->d_mask, stream)) return fail(AZ_ERR_HIP, "clear launch failed");
-    for (int ply = 0; ply < n_plies; ply++) {
-        hipLaunchKernelGGL(k_masked_actions, dim3(blocks), dim3(256), 0, st, e->d_mask, d_openings + (size_t)ply * n, n,
-                           e->d_actions);
-        if (e->ops->make_move(e->P, e->d_actions, stream)) return fail(AZ_ERR_HIP, "make_move launch failed");
-    }
-    if (hipGetLastError() != hipSuccess) return fail(AZ_ERR_HIP, "restart launch failed");
+    if (e->ops->restart(e->P, d_openings, n_plies, d_count, stream)) return fail(AZ_ERR_HIP, "restart launch failed");
     return AZ_OK;
 }
 

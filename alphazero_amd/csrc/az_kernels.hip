@@ -1216,6 +1216,23 @@ __global__ __launch_bounds__(64) void k_expand_backup(AzParams P, const float *d
     }
 }
 
+// first maximum of the root's visit counts, -1 for an idle tree or an unexpanded root
+template <int E> __device__ __forceinline__ int greedy_action(const AzParams &P, const AzTree *T, int tree, int lane)
+{
+    const int root = uni(T->root);
+    if (uni(T->active) == 0 || root < 0) return -1;
+    int n[E];
+    ld_i32<E>(rec_ptr(P, tree, root), OFF_N, lane, n);
+    int best = -1, bk = 0;
+#pragma unroll
+    for (int k = 0; k < E; k++)
+        if (lane * E + k < SIZE && n[k] > best) { best = n[k]; bk = k; }
+    const int m = wave_max_i32(best);
+    const unsigned long long mask = __ballot(best == m);
+    const int wl = __ffsll((long long)mask) - 1;
+    return wl * E + lane_bcast_i32(bk, wl);
+}
+
 // ------------------------------------------------------------------ make_move
 // Cmcts::make_move (mcts/src/cmcts.cpp:284-294): apply the move to the state,
 // keep the chosen child's subtree (Node::make_move, node.cpp:147-158) and free
@@ -1225,6 +1242,8 @@ __global__ __launch_bounds__(64) void k_expand_backup(AzParams P, const float *d
 // slot); parents inside the current 64-slot chunk are resolved by iterating the
 // chunk to a fixed point.  The list is compacted in place and dead slots go
 // back on the free stack.
+// d_actions == nullptr: every active tree plays the first maximum of its root's
+// visit counts (pi.argmax() followed by make_move, src/eval.py:192-193)
 __global__ __launch_bounds__(64) void k_make_move(AzParams P, const int *d_actions)
 {
     constexpr int E = EPL;
@@ -1232,7 +1251,7 @@ __global__ __launch_bounds__(64) void k_make_move(AzParams P, const int *d_actio
     const int tree = blockIdx.x;
     const int lane = threadIdx.x;
     AzTree *T = &P.trees[tree];
-    const int a = uni(d_actions[tree]);
+    const int a = d_actions != nullptr ? uni(d_actions[tree]) : greedy_action<E>(P, T, tree, lane);
     if (a < 0) return;
     WState s;
     load_state<E>(P, tree, lane, s);
@@ -1339,29 +1358,61 @@ __global__ __launch_bounds__(64) void k_clear(AzParams P, const unsigned char *d
     }
 }
 
+// What a game loop does once a game is over (src/self_play.py:86-91: mcts.clear(),
+// then tools.make_init_moves, src/tools.py:41-44), for every tree whose game is
+// over, in one launch: Cmcts::clear as above, then the opening moves.  On the
+// empty tree Cmcts::make_move (cmcts.cpp:284-294) only changes the state.
+__global__ __launch_bounds__(64) void k_restart(AzParams P, const int *d_openings, int n_plies, int *d_count)
+{
+    constexpr int E = EPL;
+    const int tree = blockIdx.x;
+    const int lane = threadIdx.x;
+    AzTree *T = &P.trees[tree];
+    if (unif(T->winner) == -1.f) return;
+    const size_t tbase = (size_t)tree * P.cap;
+    const int n = uni(T->n_order);
+    const int free_top = uni(T->free_top);
+    for (int i = lane; i < n; i += 64) {
+        const int idx = P.order[tbase + i];
+        P.free_stack[tbase + free_top + i] = idx;
+        P.parent[tbase + idx] = -2;
+    }
+    WState s;
+    s.rb = 0u; s.occ = 0u; s.player = 0; s.move_cnt = 0; s.winner = -1.f;
+    int err = 0;
+    for (int ply = 0; ply < n_plies; ply++) {
+        const int a = uni(d_openings[(size_t)ply * P.n_trees + tree]);
+        if (a < 0) continue;
+        bool ok = a < SIZE; // State::is_valid (state.cpp:29-37)
+        if (ok) ok = __ballot(lane == a / E && ((s.occ >> (a % E)) & 1u)) == 0ull;
+        if (!ok) { err = AZ_ERR_INVALID_MOVE; break; }
+        state_move<E>(s, a, lane);
+    }
+    P.rows[tree * 64 + lane] = s.rb;
+    if (lane == 0) {
+        T->root = -1;
+        T->root_n = -1;
+        T->n_order = 0;
+        T->free_top = free_top + n;
+        T->player = s.player;
+        T->move_cnt = s.move_cnt;
+        T->winner = s.winner;
+        T->err = err;
+        T->noise_row = 0;
+        T->leaf_kind = AZ_LEAF_NONE;
+        T->path_len = 0;
+        if (d_count != nullptr) atomicAdd(d_count, 1);
+    }
+}
+
 // first-maximum arg-max of the root visit counts (pi.argmax(), src/eval.py:192)
 __global__ __launch_bounds__(64) void k_select_greedy(AzParams P, int *d_actions)
 {
     constexpr int E = EPL;
     const int tree = blockIdx.x;
     const int lane = threadIdx.x;
-    const AzTree *T = &P.trees[tree];
-    const int root = uni(T->root);
-    if (uni(T->active) == 0 || root < 0) {
-        if (lane == 0) d_actions[tree] = -1;
-        return;
-    }
-    int n[E];
-    ld_i32<E>(rec_ptr(P, tree, root), OFF_N, lane, n);
-    int best = -1, bk = 0;
-#pragma unroll
-    for (int k = 0; k < E; k++)
-        if (lane * E + k < SIZE && n[k] > best) { best = n[k]; bk = k; }
-    const int m = wave_max_i32(best);
-    const unsigned long long mask = __ballot(best == m);
-    const int wl = __ffsll((long long)mask) - 1;
-    const int wk = lane_bcast_i32(bk, wl);
-    if (lane == 0) d_actions[tree] = wl * E + wk;
+    const int a = greedy_action<E>(P, &P.trees[tree], tree, lane);
+    if (lane == 0) d_actions[tree] = a;
 }
 
 // Node::counts / nodeN of every root (node.cpp:160-164) into dense arrays
@@ -1602,6 +1653,11 @@ int l_clear(const AzParams &P, const unsigned char *d_mask, void *stream)
     hipLaunchKernelGGL(k_clear, dim3(P.n_trees), dim3(64), 0, (hipStream_t)stream, P, d_mask);
     return launch_status();
 }
+int l_restart(const AzParams &P, const int *d_openings, int n_plies, int *d_count, void *stream)
+{
+    hipLaunchKernelGGL(k_restart, dim3(P.n_trees), dim3(64), 0, (hipStream_t)stream, P, d_openings, n_plies, d_count);
+    return launch_status();
+}
 int l_select_greedy(const AzParams &P, int *d_actions, void *stream)
 {
     hipLaunchKernelGGL(k_select_greedy, dim3(P.n_trees), dim3(64), 0, (hipStream_t)stream, P, d_actions);
@@ -1636,7 +1692,7 @@ extern "C" const AzShapeOps *AZ_CAT(az_shape_ops_, AZ_S)(void)
 {
     static const AzShapeOps ops = {
         AZ_S, SP, l_simulate_fused, l_select, l_expand_backup, l_make_move, l_clear, l_select_greedy, l_get_counts,
-        l_choose_moves, l_dirichlet,
+        l_choose_moves, l_dirichlet, l_restart,
     };
     return &ops;
 }

@@ -76,6 +76,7 @@ SYMBOLS = [
     ("az_get_pool_usage", _i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
     ("az_sync_check", _i, [_vp, _vp]),
     ("az_sync_states", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("az_make_move_greedy", _i, [_vp, _vp]),
     ("az_restart_finished", _i, [_vp, _vp, _i, _vp, _vp]),
     ("az_timing_mark", _i, [_vp, _i, _i, _vp]),
     ("az_timing_elapsed", _i, [_vp, _i, C.POINTER(_f)]),
@@ -321,6 +322,10 @@ class Engine:
         u, m = C.c_int(), C.c_int()
         self._check(self.L.az_get_pool_usage(self.h, tree, C.byref(u), C.byref(m)))
         return u.value, m.value
+
+    def make_move_greedy(self, stream=None):
+        """argmax of the root visit counts + make_move for every active tree, on the GPU."""
+        self._check(self.L.az_make_move_greedy(self.h, stream))
 
     def restart_finished(self, d_openings, n_plies, d_count=None, stream=None):
         """clear + opening moves for every finished game, on the GPU (device pointers)."""

@@ -4,9 +4,10 @@
 Workload (tree-kernel isolation, the configuration the metric is quoted on): 1024 concurrent
 trees per GPU, 800 simulations per move, uniform-prior evaluator (p = 1/225,
 v = 0) computed inside the kernel, cpuct = 4, eps = 0.  One "step" = one move
-of every tree: simulate(800) -> greedy move choice -> make_move (re-rooting +
-node-pool reclamation); finished games are cleared and restarted from their
-two-ply opening inside the timed region.  All inputs live in HBM.
+of every tree: simulate(800) -> greedy move choice + make_move (re-rooting +
+node-pool reclamation) -> finished games cleared and restarted from their
+two-ply opening, all inside the timed region and all on the GPU stream.
+All inputs live in HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
@@ -122,7 +123,6 @@ def main():
             eng.make_move(act, stream)
 
     open_games()
-    d_actions = torch.empty(B, dtype=torch.int32, device=dev)
     d_openings = torch.from_numpy(op).to(dev)                      # [2][B]
     d_restarts = torch.zeros(1, dtype=torch.int32, device=dev)
     timed_slots = []
@@ -137,8 +137,7 @@ def main():
         if timed:
             eng.timing_mark(len(timed_slots), 1, stream)
             timed_slots.append(len(timed_slots))
-        eng.select_greedy(d_actions.data_ptr(), stream)
-        eng.make_move_device(d_actions.data_ptr(), stream)
+        eng.make_move_greedy(stream)
         eng.restart_finished(d_openings.data_ptr(), 2, d_restarts.data_ptr(), stream)
 
     def barrier():

@@ -100,6 +100,11 @@ int az_get_states(az_engine *e, int *player, int *move_cnt, float *winner);
 int az_clear(az_engine *e, int tree);
 /* clear the trees whose mask byte is non-zero (host array of n_trees) */
 int az_clear_masked(az_engine *e, const unsigned char *mask);
+/* pi.argmax() followed by make_move (src/eval.py:192-193, the greedy branch of
+ * src/self_play.py:159-165) for every active tree with an expanded root, in one
+ * launch: the move is the first maximum of the root's visit counts.
+ * Asynchronous on `stream`. */
+int az_make_move_greedy(az_engine *e, void *stream);
 /* What a game loop does with a finished game (src/self_play.py:86-91: mcts.clear()
  * then tools.make_init_moves, src/tools.py:41-44) for every tree whose game is
  * over, without a host round trip: Cmcts::clear, then the moves

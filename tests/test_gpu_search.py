@@ -234,8 +234,9 @@ def test_clear_and_reuse():
 
 
 def test_restart_finished_on_device_equals_host_clear_and_openings():
-    """az_restart_finished (clear + opening moves of finished games without a host
-    round trip) against az_clear_masked + az_make_move from the host on a twin engine."""
+    """az_make_move_greedy and az_restart_finished (greedy move, then clear + opening
+    moves of finished games, without a host round trip) against argmax +
+    az_make_move + az_clear_masked from the host on a twin engine."""
     import torch
     from alphazero_amd import engine as E
 
@@ -255,11 +256,12 @@ def test_restart_finished_on_device_equals_host_clear_and_openings():
         for k, eng in enumerate(engines):
             eng.simulate_fused(sims, eval_kind=E.EVAL_HASH, hash_seed=21)
             counts, root_n = eng.get_counts()
-            eng.make_move(counts.argmax(axis=1).astype(np.int32))
             if k == 0:
+                eng.make_move_greedy()  # first maximum of the visit counts, chosen on the GPU
                 eng.restart_finished(d_open.data_ptr(), 2, d_count.data_ptr())
                 eng.sync_check()
             else:
+                eng.make_move(counts.argmax(axis=1).astype(np.int32))
                 fin = eng.get_states()[2] != -1.0
                 restarted += int(fin.sum())
                 if fin.any():

@@ -749,10 +749,12 @@ __device__ __forceinline__ int pop_free(const AzParams &P, size_t tbase, int &fr
 // separately rounded fp64 operations, kept as such: w1 = W - 1.0 at select,
 // W = w1 + (value + 1.0) at backup; only the final W is stored because no other
 // search of this tree can observe the intermediate.
-#ifdef AZ_NO_PREFETCH
-constexpr bool PREFETCH_NEXT = false;
+// EARLY_LOAD: request the likely next root pick's child record one search ahead
+// (-DAZ_NO_EARLY_LOAD builds the kernel without it, for A/B timing)
+#ifdef AZ_NO_EARLY_LOAD
+constexpr bool EARLY_LOAD = false;
 #else
-constexpr bool PREFETCH_NEXT = true;
+constexpr bool EARLY_LOAD = true;
 #endif
 // EVAL / MIX: see evaluate() and mix_prior(); the launcher picks the instance,
 // so the evaluator and noise tests leave the search loop.
@@ -874,7 +876,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             double uk[E];
             scan_root<E>(R, C, sq_root, s.occ, tid, c, uk);
             pk = finish_pick<WPT, E>(c, tid, s_slots, phase);
-            if constexpr (WPT == 1 && PREFETCH_NEXT)
+            if constexpr (WPT == 1 && EARLY_LOAD)
                 if (AZ_LIKELY(pk.a >= 0)) runner_up<E>(R, uk, pk.a, tid, pf_link, pf_n);
         }
         STAMP(0);
@@ -923,7 +925,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             NodeRegs<E> nd;
             // (links are unique per tree: an equal link is that very node, and what was
             // loaded is current because no search has run since)
-            const bool piped = WPT == 1 && PREFETCH_NEXT && cur >= 0 && pk.link == nx_link;
+            const bool piped = WPT == 1 && EARLY_LOAD && cur >= 0 && pk.link == nx_link;
             if (cur >= 0 && !piped) load_node<E, false>(P, tree, cur, tid, fresh, nd);
             state_move<E>(s, pk.a, tid);
             STAMP(1);
@@ -978,7 +980,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             }
         } while (leaf == GO);
 
-        if constexpr (WPT == 1 && PREFETCH_NEXT) {
+        if constexpr (WPT == 1 && EARLY_LOAD) {
             // requested now, after this search's last load (loads return in order: an
             // earlier request would hold up the descent's own), used by the next search
             if (pf_link > 0) load_node<E, false>(P, tree, pf_link - 1, tid, pf_n <= 1, nx);

@@ -92,6 +92,12 @@ struct Slot { // LDS exchange record of one wavefront
 #define AZ_LIKELY(x) __builtin_expect(!!(x), 1)
 #define AZ_UNLIKELY(x) __builtin_expect(!!(x), 0)
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Thread and position inside the thread that hold action a (thread-blocked, E
+// actions per thread); unsigned arithmetic: a shift and a mask for E a power of
+// two, without the sign fix-up of an int division (an action is never negative
+// where these are used; a negative one matches no thread).
+template <int E> __device__ __forceinline__ int owner_of(int a) { return (int)((unsigned)a / (unsigned)E); }
+template <int E> __device__ __forceinline__ int slot_of(int a) { return (int)((unsigned)a % (unsigned)E); }
 __device__ __forceinline__ float unif(float v)
 {
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
@@ -348,9 +354,9 @@ __device__ __noinline__ int scan_order_winner(unsigned h, unsigned v, unsigned d
 template <int E> __device__ __forceinline__ void state_move(WState &s, int a, int tid)
 {
     const int lane = tid & 63;
-    const int r = a / S, c = a - r * S;
+    const int r = (int)((unsigned)a / (unsigned)S), c = a - r * S;
     if (lane == s.player * 32 + r) s.rb |= 1u << c;
-    if (tid == a / E) s.occ |= 1u << (a % E);
+    if (tid == owner_of<E>(a)) s.occ |= 1u << (slot_of<E>(a));
     s.player = s.player ? 0 : 1; // state.cpp:89
     s.move_cnt += 1;
     if (AZ_UNLIKELY(s.move_cnt < 9)) return;  // state.cpp:158-159
@@ -510,7 +516,7 @@ __device__ __forceinline__ void runner_up(const NodeRegs<E> &R, const double (&u
                                           int &n2)
 {
     constexpr int KM = E <= 2 ? 1 : E <= 4 ? 3 : 7; // bits that hold the position
-    const int wk = tid == win_a / E ? win_a % E : -1;
+    const int wk = tid == owner_of<E>(win_a) ? slot_of<E>(win_a) : -1;
     int best = INT_MIN;
 #pragma unroll
     for (int k = 0; k < E; k++) {
@@ -790,7 +796,9 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
     int noise_row = 0;
     int err = 0;
     const size_t tbase = (size_t)tree * P.cap;
-    unsigned long long n_sims = 0, n_exp = 0, n_term = 0, n_sel = 0;
+    // (the first three are bounded by the int n_total; select calls are added once per search)
+    unsigned n_sims = 0, n_exp = 0, n_term = 0;
+    unsigned long long n_sel = 0;
 
     NodeRegs<E> R;
     RootCache<E> C;
@@ -885,15 +893,14 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
         pf_last = pf_link;
 #endif
         if (AZ_UNLIKELY(pk.a < 0)) { err = AZ_ERR_NO_ACTION; break; }
-        n_sel++;
         const int root_a = pk.a;
-        const bool root_owner = tid == root_a / E;
+        const bool root_owner = tid == owner_of<E>(root_a);
         // the visit and the virtual loss (node.cpp:116-118) of the picked action, as
         // unconditional additions of 0 or 1 to all of a thread's actions (x + 0.0 and
         // x - 0.0 are x for these values): two selects and three additions per
         // action, no branch and no select of the results
         {
-            const int root_k = root_a % E;
+            const int root_k = slot_of<E>(root_a);
 #pragma unroll
             for (int k = 0; k < E; k++) {
                 const bool hit = root_owner && root_k == k;
@@ -951,19 +958,18 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
                 if (AZ_UNLIKELY(pk.a < 0)) {
                     leaf = NO_ACTION;
                 } else {
-                    n_sel++;
                     if (fresh) { // first select on this node: materialise its statistics
                         // (from registers of their own: reusing the load targets would
                         // make later loads wait for these stores to complete)
                         NodeRegs<E> z;
 #pragma unroll
                         for (int k = 0; k < E; k++) {
-                            z.n[k] = (tid == pk.a / E && k == pk.a % E) ? 1 : 0;
+                            z.n[k] = (tid == owner_of<E>(pk.a) && k == slot_of<E>(pk.a)) ? 1 : 0;
                             z.link[k] = 0;
                             z.w[k] = 0.;
                         }
                         store_stats<E>(P, tree, cur, tid, z);
-                    } else if (tid == pk.a / E) {
+                    } else if (tid == owner_of<E>(pk.a)) {
                         *reinterpret_cast<int *>(arena_ptr(P, tree) + (rec_off(cur) + OFF_N + (unsigned)pk.a * 4u)) = pk.n + 1;
                     }
                     // (lane == depth matches no lane once depth >= 64: the register write is
@@ -1002,11 +1008,11 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             mix_prior<E, MIX>(P, pr, false, noise_row, tid, pp);
             if (MIX != 0 && P.noise != nullptr) noise_row++;
             st_f64<E>(arena_ptr(P, tree), rec_off(slot) + OFF_P, tid, pp); // statistics stay implicit zeros
-            if (tid == parent_a / E) {
+            if (tid == owner_of<E>(parent_a)) {
                 if (depth == 0) {
 #pragma unroll
                     for (int k = 0; k < E; k++)
-                        if (k == parent_a % E) R.link[k] = slot + 1;
+                        if (k == slot_of<E>(parent_a)) R.link[k] = slot + 1;
                 } else {
                     *reinterpret_cast<int *>(arena_ptr(P, tree) + (rec_off(parent_slot) + OFF_LINK + (unsigned)parent_a * 4u)) =
                         slot + 1;
@@ -1024,7 +1030,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
         int d = depth - 1;
         for (; __builtin_expect(d >= 64, 0); --d) { // entries spilled to LDS (rare)
             const int act = s_act[d - 64];
-            if (tid == act / E)
+            if (tid == owner_of<E>(act))
                 *reinterpret_cast<double *>(arena_ptr(P, tree) + (rec_off(s_node[d - 64]) + OFF_W + (unsigned)act * 8u)) =
                     s_w1[d - 64] + ((double)value + 1.);
             value = -value;
@@ -1033,7 +1039,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             int node, act;
             double w1;
             path_get(path, d, node, act, w1);
-            if (tid == act / E)
+            if (tid == owner_of<E>(act))
                 *reinterpret_cast<double *>(arena_ptr(P, tree) + (rec_off(node) + OFF_W + (unsigned)act * 8u)) =
                     w1 + ((double)value + 1.);
             value = -value;
@@ -1041,13 +1047,14 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
         if (root_owner) { // the two divisions of this search: W/N and 1/(N+1)
 #pragma unroll
             for (int k = 0; k < E; k++)
-                if (k == root_a % E) {
+                if (k == slot_of<E>(root_a)) {
                     R.w[k] += (double)value + 1.;
                     C.q[k] = R.w[k] / (double)R.n[k];
                     C.rinv[k] = 1. / C.np1[k];
                 }
         }
         n_sims++;
+        n_sel += (unsigned)(depth + 1); // Node::select calls of this search: the root's and one per level below
         STAMP(6);
     }
 #ifdef AZ_PF_STATS
@@ -1106,9 +1113,9 @@ __global__ __launch_bounds__(64) void k_select(AzParams P, float *d_boards, int 
         if (fresh) {
 #pragma unroll
             for (int k = 0; k < E; k++)
-                if (lane == pk.a / E && k == pk.a % E) { nd.n[k] = 1; nd.w[k] = -1.; }
+                if (lane == owner_of<E>(pk.a) && k == slot_of<E>(pk.a)) { nd.n[k] = 1; nd.w[k] = -1.; }
             store_stats<E>(P, tree, cur, lane, nd);
-        } else if (lane == pk.a / E) {
+        } else if (lane == owner_of<E>(pk.a)) {
             reinterpret_cast<int *>(rec + OFF_N)[pk.a] = pk.n + 1;
             reinterpret_cast<double *>(rec + OFF_W)[pk.a] = pk.w - 1.;
         }
@@ -1260,7 +1267,7 @@ __global__ __launch_bounds__(64) void k_make_move(AzParams P, const int *d_actio
     // State::is_valid (state.cpp:29-37)
     bool ok = a < SIZE;
     if (ok) {
-        const unsigned long long occupied = __ballot(lane == a / E && ((s.occ >> (a % E)) & 1u));
+        const unsigned long long occupied = __ballot(lane == owner_of<E>(a) && ((s.occ >> (slot_of<E>(a))) & 1u));
         ok = occupied == 0ull;
     }
     if (!ok) {
@@ -1386,7 +1393,7 @@ __global__ __launch_bounds__(64) void k_restart(AzParams P, const int *d_opening
         const int a = uni(d_openings[(size_t)ply * P.n_trees + tree]);
         if (a < 0) continue;
         bool ok = a < SIZE; // State::is_valid (state.cpp:29-37)
-        if (ok) ok = __ballot(lane == a / E && ((s.occ >> (a % E)) & 1u)) == 0ull;
+        if (ok) ok = __ballot(lane == owner_of<E>(a) && ((s.occ >> (slot_of<E>(a))) & 1u)) == 0ull;
         if (!ok) { err = AZ_ERR_INVALID_MOVE; break; }
         state_move<E>(s, a, lane);
     }

@@ -57,6 +57,7 @@ def cpu_baseline():
     games, plies = 96 * cores, 50  # about 15 s on 16 host threads
     ev = O.uniform_evaluator(np.float32(1.0 / SIZE))
     total, secs = O.baseline_games(SHAPE, games, cores, plies, SIMS, CPUCT, ev)
+    one_total, one_secs = O.baseline_games(SHAPE, 12, 1, plies, SIMS, CPUCT, ev)  # about 2 s
     return {
         "value": total / secs,
         "unit": "sims/s",
@@ -64,6 +65,7 @@ def cpu_baseline():
         "kind": "port",
         "sample": f"{games} independent games x {plies} plies x {SIMS} sims, one game per thread, "
                   f"{total} sims in {secs:.2f} s",
+        "single_thread_value": one_total / one_secs,
     }
 
 

@@ -532,6 +532,25 @@ def gather_samples(samples, group=None):
     return np.concatenate(chunks) if chunks else samples
 
 
+def broadcast_parameters(tensors, src=0, group=None):
+    """The evaluator replicas of all ranks take rank `src`'s weights (one
+    broadcast per tensor, in place; RCCL with the nccl backend).  `tensors`: an
+    evaluator with a packed `params` tensor (FusedNetEvaluator), a torch module,
+    or an iterable of tensors."""
+    import torch
+    import torch.distributed as dist
+
+    if hasattr(tensors, "params") and isinstance(tensors.params, torch.Tensor):
+        tensors = [tensors.params]
+    elif isinstance(tensors, torch.nn.Module):
+        tensors = list(tensors.parameters()) + list(tensors.buffers())
+    tensors = list(tensors)
+    if dist.is_available() and dist.is_initialized():
+        for t in tensors:
+            dist.broadcast(t.data, src=src, group=group)
+    return tensors
+
+
 def reduce_counters(values, group=None):
     """Sum of per-rank counters (sims, expansions, wins ...) over all ranks."""
     import torch

@@ -41,6 +41,14 @@ def _worker(rank, world, port, out_dir):
     mine = np.concatenate(recs) if recs else np.zeros(0, dt)
     everything = sp.gather_samples(mine)
     counters = sp.reduce_counters([len(mine), hi - lo, rank])
+    # evaluator replicas start from rank 0's weights
+    import torch
+
+    torch.manual_seed(100 + rank)
+    net = torch.nn.Sequential(torch.nn.Conv2d(2, 4, 3), torch.nn.BatchNorm2d(4))
+    sp.broadcast_parameters(net)
+    flat = torch.cat([t.detach().reshape(-1).double() for t in list(net.parameters()) + list(net.buffers())])
+    np.save(os.path.join(out_dir, f"net_{rank}.npy"), flat.numpy())
     np.save(os.path.join(out_dir, f"all_{rank}.npy"), everything)
     np.save(os.path.join(out_dir, f"cnt_{rank}.npy"), counters)
     dist.barrier()
@@ -59,6 +67,8 @@ def test_two_rank_gather_and_reduce(tmp_path):
     # 7 games, game g has g+1 records, rank order preserved
     assert len(a0) == sum(range(1, 8))
     assert a0["r"].tolist() == [float(g) for g in range(7) for _ in range(g + 1)]
+    n0, n1 = np.load(tmp_path / "net_0.npy"), np.load(tmp_path / "net_1.npy")
+    assert n0.size > 0 and np.array_equal(n0, n1)
     c0, c1 = np.load(tmp_path / "cnt_0.npy"), np.load(tmp_path / "cnt_1.npy")
     assert c0.tolist() == c1.tolist() == [28.0, 7.0, 1.0]
 

@@ -58,6 +58,8 @@ def main():
     for seed in (0, 1):
         torch.manual_seed(seed)
         nets.append(FusedNetEvaluator(PolicyValueNet(args.shape).eval(), args.shape, dev, name=f"seed{seed}"))
+    for ev in nets:
+        sp.broadcast_parameters(ev)  # every rank plays with rank 0's weights
     b0 = sp.TreeBatch(G, args.shape, nets[0], cpuct=4.0, eps=args.eps, nodes_per_tree=nodes, device=local_rank,
                       noise_seed=rank)
     b1 = sp.TreeBatch(G, args.shape, nets[0 if args.mode == "selfplay" else 1], cpuct=4.0, eps=args.eps,

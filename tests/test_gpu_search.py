@@ -143,6 +143,19 @@ def test_fused_20x20_at_8192_trees():
     _play_fused(20, B=8192, sims=100, plies=3, ev_kind="hash", eps=0.25, cpuct=4.0, nodes=480)
 
 
+def test_fused_paths_deeper_than_64_levels():
+    # cpuct = 0 with a constant value: every score ties, the first legal action wins at every
+    # level and each search extends one line by a node -- down to level 80 on 20x20 (the
+    # part of a search path beyond 64 levels is kept in LDS instead of registers)
+    st = _play_fused(20, B=2, sims=500, plies=2, ev_kind="uniform", eps=0.0, cpuct=0.0)
+    assert st["select_calls"] / st["sims"] > 30
+
+
+def test_fused_more_visits_than_the_sqrt_table_holds():
+    # nodeN beyond the 2048-entry table of sqrt(nodeN + 1e-8): the operation itself takes over
+    _play_fused(9, B=2, sims=2600, plies=2, ev_kind="hash", eps=0.0, cpuct=4.0, nodes=2600 * 3)
+
+
 def test_fused_small_board_to_the_end():
     # 6x6 / 7x7 games run into terminals, draws and full boards inside the search
     for S in (6, 7):

@@ -203,3 +203,26 @@ def test_step_8192_trees_sampled_against_oracle():
         for g, t in trees.items():
             assert float(winner[g]) == t.winner
     batch.close()
+
+
+def test_step_paths_deeper_than_64_levels():
+    """cpuct = 0 and a constant value: all scores tie, every search extends the line of
+    first legal actions by one node (level 80 on 20x20), through the stepped kernels."""
+    import torch
+    from alphazero_amd import engine as E
+
+    S, size, sims = 20, 400, 450
+    p = np.full(size, np.float32(1.0 / size), np.float32)
+    eng = E.Engine(2, S, nodes_per_tree=sims + 8, cpuct=0.0)
+    eng.set_eps(0.0)
+    _step_sims(eng, torch, sims, lambda b: (np.float32(0.0), p))
+    ot = O.OracleTree(S, cpuct=0.0)
+    ot.set_eps(0.0)
+    ot.simulate(sims, O.uniform_evaluator(np.float32(1.0 / size)))
+    counts, root_n = eng.get_counts()
+    assert root_n[0] == ot.root_n() and np.array_equal(counts[0].astype(np.int64), ot.root_counts())
+    assert np.array_equal(counts[1], counts[0])
+    st, want = eng.get_stats(), ot.stats()
+    assert st["select_calls"] == 2 * want["select_calls"] and st["terminals"] == 2 * want["terminals"]
+    assert want["select_calls"] / want["sims"] > 30
+    eng.close()

@@ -288,3 +288,26 @@ def test_restart_finished_on_device_equals_host_clear_and_openings():
     assert int(d_count.item()) == restarted
     for eng in engines:
         eng.close()
+
+
+def test_noise_table_too_short_is_reported():
+    """Every expansion of a simulate() call takes the next row of the noise table
+    (node.cpp:38 draws a fresh Dirichlet vector each time): running out of rows is an
+    error, for the fused and for the stepped search, and the tree keeps its last valid state."""
+    from alphazero_amd import engine as E
+
+    S, size = 7, 49
+    noise = _noise_table(10, size, 0.3, 1)
+    for stepped in (False, True):
+        eng = E.Engine(2, S, nodes_per_tree=200, cpuct=4.0)
+        eng.set_eps(0.25)
+        eng.set_noise_table(noise)
+        with pytest.raises(E.EngineError) as ei:
+            if stepped:
+                import torch
+                from test_gpu_step import _step_sims
+                _step_sims(eng, torch, 30, lambda b: O.hash_eval(S, 3, b))
+            else:
+                eng.simulate_fused(30, eval_kind=E.EVAL_HASH, hash_seed=3)
+        assert ei.value.code == E.ERR_NOISE_ROWS
+        eng.close()

@@ -311,3 +311,21 @@ def test_noise_table_too_short_is_reported():
                 eng.simulate_fused(30, eval_kind=E.EVAL_HASH, hash_seed=3)
         assert ei.value.code == E.ERR_NOISE_ROWS
         eng.close()
+
+
+@pytest.mark.timeout(400)
+def test_fused_random_configurations():
+    """Differential sweep: board edge, search length, evaluator, noise share and cpuct
+    drawn at random (fixed seed); every tree's root statistics, states and the
+    counters against the oracle, as in the fixed cases above.  (Single worker only:
+    with threads > 1 the oracle, like the reference, runs real concurrent threads and
+    is not deterministic; that mode's arithmetic is covered by
+    test_fused_thread_fanout_rounding.)"""
+    rng = np.random.default_rng(20240611)
+    for _ in range(60):
+        S = int(rng.integers(5, 21))
+        sims = int(rng.integers(20, 220))
+        _play_fused(S, B=3, sims=sims, plies=int(rng.integers(2, 6)),
+                    ev_kind=str(rng.choice(["uniform", "hash"])), eps=float(rng.choice([0.0, 0.1, 0.25, 1.0])),
+                    cpuct=float(rng.choice([0.0, 0.5, 4.0, 10.0])), nodes=sims * 8 + 64,
+                    seed=int(rng.integers(1, 1000)))

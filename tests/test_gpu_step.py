@@ -226,3 +226,55 @@ def test_step_paths_deeper_than_64_levels():
     assert st["select_calls"] == 2 * want["select_calls"] and st["terminals"] == 2 * want["terminals"]
     assert want["select_calls"] / want["sims"] > 30
     eng.close()
+
+
+@pytest.mark.timeout(400)
+def test_step_random_configurations():
+    """Differential sweep of the stepped path (az_select / az_expand_backup) against the
+    oracle: board edge, search length, noise share, cpuct, log / linear priors at random."""
+    import torch
+    from alphazero_amd import engine as E
+
+    rng = np.random.default_rng(77001)
+    for _ in range(16):
+        S = int(rng.integers(5, 21))
+        size = S * S
+        sims, plies, B = int(rng.integers(10, 90)), int(rng.integers(1, 4)), 2
+        eps = float(rng.choice([0.0, 0.25, 1.0]))
+        cpuct = float(rng.choice([0.0, 1.0, 4.0]))
+        seed = int(rng.integers(1, 1000))
+        eng = E.Engine(B, S, nodes_per_tree=sims * (plies + 1) + 16, cpuct=cpuct)
+        eng.set_alpha_default()
+        eng.set_eps(eps)
+        noise = None
+        if eps > 0:
+            noise = np.random.default_rng(seed).dirichlet(np.full(size, eng.get_alpha()), size=sims + 2)
+            eng.set_noise_table(noise)
+        ev = O.hash_evaluator(seed)
+        trees = []
+        for g in range(B):
+            t = O.OracleTree(S, cpuct=cpuct)
+            t.set_alpha_default()
+            t.set_eps(eps)
+            trees.append(t)
+        act = np.array([O.opening(size, g + seed)[0] for g in range(B)], np.int32)
+        eng.make_move(act)
+        for t, a in zip(trees, act):
+            t.make_move(int(a))
+        for ply in range(plies):
+            _step_sims(eng, torch, sims, lambda b: O.hash_eval(S, seed, b))
+            counts, root_n = eng.get_counts()
+            for t, ot in enumerate(trees):
+                ot.simulate(sims, ev, noise)
+                tag = (S, sims, eps, cpuct, seed, ply, t)
+                assert root_n[t] == ot.root_n(), tag
+                assert np.array_equal(counts[t].astype(np.int64), ot.root_counts()), tag
+                node = eng.get_node(t, [])
+                assert np.array_equal(node[2], ot.root_w()) and np.array_equal(node[3], ot.root_p()), tag
+            act = counts.argmax(axis=1).astype(np.int32)
+            eng.make_move(act)
+            for ot, a in zip(trees, act):
+                ot.make_move(int(a))
+            if any(ot.winner != -1 for ot in trees):
+                break
+        eng.close()

@@ -231,7 +231,7 @@ def test_step_paths_deeper_than_64_levels():
 @pytest.mark.timeout(400)
 def test_step_random_configurations():
     """Differential sweep of the stepped path (az_select / az_expand_backup) against the
-    oracle: board edge, search length, noise share, cpuct, log / linear priors at random."""
+    oracle: board edge, search length, noise share and cpuct at random."""
     import torch
     from alphazero_amd import engine as E
 

@@ -99,6 +99,13 @@ def main():
         "tree_kernel_sims_per_s": args.trees / (t_tree / n_steps / 1e3),
         "mean_select_depth": st["select_calls"] / max(1, st["sims"]),
         "device_bytes": eng.device_bytes(),
+        # 3x3 convolutions of the reference configuration (4 + 2 + 2 layers of 16 channels, 2 input
+        # planes) + heads, 2 flops per multiply-add; priced against the dense f32 matrix-core peak
+        "evaluator_roofline": {
+            "bound": "mfma", "unit": "TFLOP/s", "peak": 157.3,
+            "achieved": args.trees * 2.0 * args.shape ** 2 * (9 * 2 * 16 + 7 * 9 * 16 * 16 + 9 * 16 + 16)
+                        / (t_eval / n_steps / 1e3) / 1e12,
+        },
     }))
     tb.close()
 

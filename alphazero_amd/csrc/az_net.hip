@@ -136,7 +136,9 @@ __device__ __forceinline__ void policy_head(const float *src, const float *p_pol
     for (int p = tid; p < G::SIZE; p += 256) {
         const int ctr = (p / S + 1) * G::ROW + p % S + 1;
         float acc = p_policy[9 * CH];
-#pragma unroll
+        // (taps not unrolled: with all 144 operand reads of a pixel hoisted at once the
+        // kernel runs out of registers and spills; 4 % slower at 15x15, 18 % at 20x20)
+#pragma unroll 1
         for (int tap = 0; tap < 9; tap++) {
             const int off = ctr + (tap / 3 - 1) * G::ROW + (tap % 3 - 1);
 #pragma unroll

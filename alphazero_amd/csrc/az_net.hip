@@ -20,6 +20,9 @@
 
 namespace {
 
+#ifndef AZ_NET_FORCE_NW
+#define AZ_NET_FORCE_NW 0
+#endif
 constexpr int CH = 16;  // conv channels of the reference configuration (config.py:15)
 constexpr int CIN = 2;  // input planes (config.py:12)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -42,6 +45,13 @@ template <int S> struct Geo {
     // channel, spread over all LDS banks (measured 5 % faster than = 16 mod 32,
     // which favours the operand reads)
     static constexpr int PS = ((PLANE + 16 * TPR + 31) / 32) * 32 + 1;
+    // Wavefronts per workgroup (= per position).  Two workgroups of four share a CU
+    // while three activation buffers fit twice into its 160 KB of LDS; on the
+    // widest boards only one workgroup fits, which then runs eight wavefronts so
+    // that every SIMD still holds two.
+    static constexpr int NW = (AZ_NET_FORCE_NW != 0) ? AZ_NET_FORCE_NW : (2 * 3 * CH * PS * 4 > 150 * 1024 ? 8 : 4);
+    static constexpr int TPW = 16 / NW;  // tiles (accumulators) per wavefront and round
+    static constexpr int NTHR = 64 * NW;
 };
 
 // packed parameter block (floats), built by the host:
@@ -76,11 +86,12 @@ __device__ __forceinline__ void conv3x3(const float *in, float *out, const Layer
 {
     using G = Geo<S>;
     const int co = lane & 15, kq = lane >> 4;
-    for (int tile0 = wave * 4; tile0 < G::NT; tile0 += 16) {
-        f32x4 acc[4];
-        int base[4];
+    constexpr int TPW = G::TPW;
+    for (int tile0 = wave * TPW; tile0 < G::NT; tile0 += 16) {
+        f32x4 acc[TPW];
+        int base[TPW];
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
+        for (int t = 0; t < TPW; t++) {
             acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if constexpr (G::FLAT) {
                 int p = (tile0 + t) * 16 + (lane & 15);
@@ -99,11 +110,11 @@ __device__ __forceinline__ void conv3x3(const float *in, float *out, const Layer
             else { const int kk = ks * 4 + kq; tap = kk < 18 ? kk >> 1 : 0; ci = kk & 1; }
             const int off = ci * G::PS + (tap / 3 - 1) * G::ROW + (tap % 3 - 1);
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+            for (int t = 0; t < TPW; t++)
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(in[base[t] + off], w.b[ks], acc[t], 0, 0, 0);
         }
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
+        for (int t = 0; t < TPW; t++) {
             const int tile = tile0 + t;
             if constexpr (G::FLAT) {
                 // accumulator register r of this lane: pixel tile*16 + kq*4 + r, channel co
@@ -133,7 +144,7 @@ __device__ __forceinline__ void policy_head(const float *src, const float *p_pol
 {
     using G = Geo<S>;
     float lmax = -INFINITY;
-    for (int p = tid; p < G::SIZE; p += 256) {
+    for (int p = tid; p < G::SIZE; p += G::NTHR) {
         const int ctr = (p / S + 1) * G::ROW + p % S + 1;
         float acc = p_policy[9 * CH];
         // (taps not unrolled: with all 144 operand reads of a pixel hoisted at once the
@@ -151,30 +162,35 @@ __device__ __forceinline__ void policy_head(const float *src, const float *p_pol
     for (int o = 1; o < 64; o <<= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
     if (lane == 0) red[wave] = lmax;
     __syncthreads();
-    lmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    lmax = red[0];
+#pragma unroll
+    for (int w = 1; w < G::NW; w++) lmax = fmaxf(lmax, red[w]);
     float lsum = 0.f;
-    for (int p = tid; p < G::SIZE; p += 256) lsum += expf(logit[p] - lmax);
+    for (int p = tid; p < G::SIZE; p += G::NTHR) lsum += expf(logit[p] - lmax);
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) lsum += __shfl_xor(lsum, o);
-    if (lane == 0) red[4 + wave] = lsum;
+    if (lane == 0) red[G::NW + wave] = lsum;
     __syncthreads();
-    const float lse = lmax + logf((red[4] + red[5]) + (red[6] + red[7]));
-    for (int p = tid; p < G::SIZE; p += 256) logp_row[p] = logit[p] - lse;
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < G::NW; w += 4) tot += (red[G::NW + w] + red[G::NW + w + 1]) + (red[G::NW + w + 2] + red[G::NW + w + 3]);
+    const float lse = lmax + logf(tot);
+    for (int p = tid; p < G::SIZE; p += G::NTHR) logp_row[p] = logit[p] - lse;
     __syncthreads(); // scratch and the branch buffers are free again
 }
 
 template <int S>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_eval(const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol,
+__global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_eval(const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol,
                                                   int val, float *value_out, float *logp_out)
 {
     using G = Geo<S>;
     extern __shared__ float lds[];
     float *A = lds, *B = lds + CH * G::PS, *C = lds + 2 * CH * G::PS;
-    float *red = lds + 3 * CH * G::PS; // [8] reduction scratch + logits [SIZE]
-    float *logit = red + 8;
+    float *red = lds + 3 * CH * G::PS; // [2 * NW] reduction scratch + logits [SIZE]
+    float *logit = red + 2 * G::NW;
     int *todo = reinterpret_cast<int *>(logit + G::SIZE); // [ceil(n / gridDim.x)] positions of this workgroup
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int i = tid; i < 3 * CH * G::PS; i += 256) lds[i] = 0.f; // halos stay zero from here on
+    for (int i = tid; i < 3 * CH * G::PS; i += G::NTHR) lds[i] = 0.f; // halos stay zero from here on
     __syncthreads();
     const int nl = front - 1 + pol + val; // 16->16 layers: trunk, policy branch, value branch
     const float *p_layers = prm + FIRST_FLOATS;
@@ -195,8 +211,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // second kernel.
     int n_mine;
     if (leaf_kind != nullptr) {
-        int *cnt = reinterpret_cast<int *>(red); // [4] per-wavefront totals (scratch is free before the first head)
-        const int per = (n + 255) / 256, lo = tid * per, hi = lo + per < n ? lo + per : n;
+        int *cnt = reinterpret_cast<int *>(red); // [NW] per-wavefront totals (scratch is free before the first head)
+        const int per = (n + G::NTHR - 1) / G::NTHR, lo = tid * per, hi = lo + per < n ? lo + per : n;
         int c = 0;
         for (int i = lo; i < hi; i++) c += leaf_kind[i] == AZ_LEAF_EXPAND;
         int incl = c; // inclusive prefix over the wavefront, then over the four wavefronts
@@ -209,7 +225,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();
         int before = incl - c, total = 0;
 #pragma unroll
-        for (int w = 0; w < 4; w++) {
+        for (int w = 0; w < G::NW; w++) {
             if (w < wave) before += cnt[w];
             total += cnt[w];
         }
@@ -227,7 +243,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int pos = leaf_kind != nullptr ? todo[it] : (int)blockIdx.x + it * (int)gridDim.x;
         // raw planes into channels 0..1 of A (channels 2..15 of A may hold stale
         // interior values of the previous position: the 2-plane layer never reads them)
-        for (int i = tid; i < CIN * G::SIZE; i += 256) {
+        for (int i = tid; i < CIN * G::SIZE; i += G::NTHR) {
             const int c = i / G::SIZE, p = i - c * G::SIZE;
             A[c * G::PS + (p / S + 1) * G::ROW + p % S + 1] = boards[(size_t)pos * CIN * G::SIZE + i];
         }
@@ -263,7 +279,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         // ---- value head: 1x1 conv + bias, board average, tanh
         float vs = 0.f;
-        for (int p = tid; p < G::SIZE; p += 256) {
+        for (int p = tid; p < G::SIZE; p += G::NTHR) {
             const int ctr = (p / S + 1) * G::ROW + p % S + 1;
 #pragma unroll
             for (int ci = 0; ci < CH; ci++) vs += p_value[ci] * head_src[ci * G::PS + ctr];
@@ -272,7 +288,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int o = 1; o < 64; o <<= 1) vs += __shfl_xor(vs, o);
         if (lane == 0) red[wave] = vs;
         __syncthreads();
-        if (tid == 0) value_out[pos] = tanhf(((red[0] + red[1]) + (red[2] + red[3])) / (float)G::SIZE + p_value[CH]);
+        if (tid == 0) {
+            float vt = 0.f;
+#pragma unroll
+            for (int w = 0; w < G::NW; w += 4) vt += (red[w] + red[w + 1]) + (red[w + 2] + red[w + 3]);
+            value_out[pos] = tanhf(vt / (float)G::SIZE + p_value[CH]);
+        }
         __syncthreads();
     }
 }
@@ -281,7 +302,7 @@ template <int S> int launch(const float *boards, const int *leaf_kind, int n, co
                             float *logp_out, hipStream_t st)
 {
     using G = Geo<S>;
-    const size_t fixed_bytes = (size_t)(3 * CH * G::PS + 8 + G::SIZE) * sizeof(float);
+    const size_t fixed_bytes = (size_t)(3 * CH * G::PS + 2 * G::NW + G::SIZE) * sizeof(float);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int per_cu = (int)(160 * 1024 / fixed_bytes) > 0 ? (int)(160 * 1024 / fixed_bytes) : 1;
@@ -296,7 +317,7 @@ template <int S> int launch(const float *boards, const int *leaf_kind, int n, co
             return AZ_ERR_HIP;
         configured = lds_bytes;
     }
-    hipLaunchKernelGGL(k_net_eval<S>, dim3(grid), dim3(256), lds_bytes, st, boards, leaf_kind, n, prm, front, pol, val, value_out,
+    hipLaunchKernelGGL(k_net_eval<S>, dim3(grid), dim3(G::NTHR), lds_bytes, st, boards, leaf_kind, n, prm, front, pol, val, value_out,
                        logp_out);
     return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
 }

@@ -66,6 +66,7 @@ class mcts:
             _raise(e)
         self._device = device
         self._params = ""
+        self._moves = []  # State::moves (state.cpp:91), shown by __repr__
         self._evaluator = None
         self.noise_seed = 0
         self._noise_key = None
@@ -177,6 +178,7 @@ class mcts:
     def clear(self):
         """cmcts.cpp:30-37: new root, empty board; parameters are kept."""
         self._eng.clear(0)
+        self._moves = []
 
     def _ensure_evaluator(self):
         if self._evaluator is None:
@@ -246,6 +248,7 @@ class mcts:
             if e.code == _E.ERR_INVALID_MOVE:
                 raise RuntimeError(f"Invalid move {int(action)}\n {self!r}!") from None  # state.cpp:86
             _raise(e)
+        self._moves.append(int(action))  # state.cpp:91
 
     def make_movexy(self, x, y):
         """cmcts.cpp:296-309"""
@@ -253,6 +256,7 @@ class mcts:
             self._eng.make_movexy(0, int(x), int(y))
         except _E.EngineError as e:
             _raise(e)
+        self._moves.append(int(y) * self._shape + int(x))
 
     def get_board(self):
         """state.cpp:39-48: float32 [2,S,S], plane 0 = side to move."""
@@ -324,6 +328,7 @@ class mcts:
         s.append("Player: x" if player == 0 else "Player: o")
         s.append({0.0: "Winner: x", 1.0: "Winner: o", -1.0: "Winner: _"}.get(winner, "Winner: draw"))
         s.append(f"Move count: {move_cnt}")
+        s.append("Moves: " + "".join(f"{m}, " for m in self._moves))
         s.append(f"Board size: {self._size}")
         s.append("Board:")
         for r in range(S):

@@ -181,8 +181,13 @@ def test_cmcts_facade_runs_reference_shaped_game(tmp_path):
     m.simulate(1)
     with pytest.raises(RuntimeError, match="Not a distribution"):
         m.get_prob()
-    assert "Move count: 0" in repr(m)
+    assert "Move count: 0" in repr(m) and "Moves: \n" in repr(m)
+    m.make_movexy(x=2, y=1)
+    m.make_move(0)
+    # State::repr (state.cpp:113-150): the move list and the board rows
+    assert f"Move count: 2\nMoves: {S + 2}, 0, \nBoard size: {S * S}\nBoard:\no _ _" in repr(m)
     m.clear()
+    assert "Moves: \n" in repr(m)
 
 
 # ---- games played by the reference's own caller functions (tests/golden/caller_games.npz)

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libazmcts.so")
+# (AZ_LIBAZMCTS: another build of the library, e.g. an experiment variant, for A/B runs)
+LIB_PATH = os.environ.get("AZ_LIBAZMCTS") or os.path.join(_HERE, "libazmcts.so")
 
 EVAL_UNIFORM, EVAL_HASH = 0, 1
 LEAF_NONE, LEAF_EXPAND, LEAF_TERMINAL = 0, 1, 2

@@ -329,3 +329,23 @@ def test_fused_random_configurations():
                     ev_kind=str(rng.choice(["uniform", "hash"])), eps=float(rng.choice([0.0, 0.1, 0.25, 1.0])),
                     cpuct=float(rng.choice([0.0, 0.5, 4.0, 10.0])), nodes=sims * 8 + 64,
                     seed=int(rng.integers(1, 1000)))
+
+
+def test_timing_slots_do_not_block():
+    """az_timing_mark / az_timing_elapsed: start and end events of several launches are
+    recorded without waiting, the times are read afterwards."""
+    from alphazero_amd import engine as E
+
+    eng = E.Engine(64, 9, nodes_per_tree=400, cpuct=4.0)
+    eng.set_eps(0.0)
+    eng.simulate_fused(5, eval_kind=E.EVAL_HASH, hash_seed=1)  # first launch pays for loading the code object
+    for slot, sims in enumerate((20, 200)):
+        eng.timing_mark(slot, 0)
+        eng.simulate_fused(sims, eval_kind=E.EVAL_HASH, hash_seed=1, sync=False)
+        eng.timing_mark(slot, 1)
+    eng.sync_check()
+    short, long_ = eng.timing_elapsed(0), eng.timing_elapsed(1)
+    assert 0 < short < long_
+    with pytest.raises(E.EngineError):
+        eng.timing_elapsed(7)  # never marked
+    eng.close()

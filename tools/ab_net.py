@@ -1,9 +1,10 @@
 import sys, os, statistics, subprocess
-sys.path.insert(0, '/root/repo')
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, ROOT)
 if len(sys.argv) > 2 and sys.argv[1] == 'child':
     import torch, numpy as np
     from alphazero_amd import engine as E
-    E.LIB_PATH = os.path.join('/root/repo/alphazero_amd', sys.argv[2])
+    E.LIB_PATH = os.path.join(ROOT, 'alphazero_amd', sys.argv[2])
     from alphazero_amd.evaluator import FusedNetEvaluator
     from alphazero_amd.model import PolicyValueNet
     S = int(sys.argv[3])

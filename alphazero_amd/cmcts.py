@@ -228,6 +228,12 @@ class mcts:
                           torch.zeros(1, dtype=torch.int32, device=dev))
         boards, kinds = self._bufs
         stream = torch.cuda.current_stream(dev).cuda_stream
+        if getattr(ev, "fused_layers", None) is not None:
+            try:  # the library's own network kernel: one call queues every step of the search
+                self._eng.simulate_net(n, ev.params.data_ptr(), ev.fused_layers, stream)
+            except _E.EngineError as e:
+                _raise(e)
+            return
         try:
             with torch.no_grad():
                 for _ in range(th_num):

@@ -67,6 +67,7 @@ struct az_engine {
     int *d_root_n = nullptr;       // [n_trees]
     double *d_noise = nullptr;     // [rows][sp]
     int noise_cap = 0;             // rows allocated at d_noise
+    char *d_stage = nullptr;       // az_simulate_net: leaf boards, codes, values, log-priors of one step
     std::vector<AzTree> h_trees;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> ev_slots; // [2 * slot + end] for az_timing_mark, created on first use
@@ -228,7 +229,7 @@ void az_destroy(az_engine *e)
     (void)hipDeviceSynchronize();
     AzParams &P = e->P;
     void *ptrs[] = {P.nodes, P.parent, P.free_stack, P.order, P.trees, P.rows,
-                    P.path_node, P.path_act, P.stamps, e->d_actions, e->d_mask, e->d_counts, e->d_root_n, e->d_noise};
+                    P.path_node, P.path_act, P.stamps, e->d_actions, e->d_mask, e->d_counts, e->d_root_n, e->d_noise, e->d_stage};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -305,6 +306,7 @@ int az_get_states(az_engine *e, int *player, int *move_cnt, float *winner)
 {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     DeviceGuard g(e->device);
+    HIP_TRY(hipDeviceSynchronize()); // work queued on any stream lands first
     if (int rc = fetch_trees(e)) return rc;
     for (int t = 0; t < e->n_trees; t++) {
         if (player) player[t] = e->h_trees[t].player;
@@ -318,6 +320,7 @@ int az_get_state(az_engine *e, int tree, int *player, int *move_cnt, float *winn
 {
     if (int rc = check_tree(e, tree)) return rc;
     DeviceGuard g(e->device);
+    HIP_TRY(hipDeviceSynchronize());
     AzTree t;
     HIP_TRY(hipMemcpy(&t, e->P.trees + tree, sizeof t, hipMemcpyDeviceToHost));
     if (player) *player = t.player;
@@ -330,6 +333,7 @@ int az_clear_masked(az_engine *e, const unsigned char *mask)
 {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     DeviceGuard g(e->device);
+    HIP_TRY(hipDeviceSynchronize()); // searches queued on any stream finish before their trees are reset
     if (mask) {
         HIP_TRY(hipMemcpy(e->d_mask, mask, e->n_trees, hipMemcpyHostToDevice));
         if (e->ops->clear(e->P, e->d_mask, nullptr)) return fail(AZ_ERR_HIP, "clear launch failed");
@@ -464,19 +468,105 @@ int az_expand_backup(az_engine *e, const float *d_value, const float *d_prior, i
     return AZ_OK;
 }
 
+// Staging of one search step between az_select, az_net_eval and az_expand_backup
+// for n trees of `size` actions: leaf boards float [n][2][size], log-priors float
+// [n][size], values float [n], leaf codes int [n]; every section 256-byte aligned.
+struct StageLayout {
+    size_t boards, logp, value, kinds, bytes;
+};
+static StageLayout stage_layout(int n, int size)
+{
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    StageLayout L;
+    L.boards = 0;
+    L.logp = up((size_t)n * 2 * size * sizeof(float));
+    L.value = L.logp + up((size_t)n * size * sizeof(float));
+    L.kinds = L.value + up((size_t)n * sizeof(float));
+    L.bytes = L.kinds + up((size_t)n * sizeof(int));
+    return L;
+}
+
+// Cmcts::simulate with the network evaluated by az_net_eval: every search step is
+// three launches on `stream` (select, network, expand + backup), the host never waits.
+static int simulate_net_steps(az_engine *e, int n, const float *d_params, int front, int pol, int val, char *stage,
+                              void *stream)
+{
+    const StageLayout L = stage_layout(e->n_trees, e->size);
+    float *boards = reinterpret_cast<float *>(stage + L.boards);
+    float *logp = reinterpret_cast<float *>(stage + L.logp);
+    float *value = reinterpret_cast<float *>(stage + L.value);
+    int *kinds = reinterpret_cast<int *>(stage + L.kinds);
+    // thread fan-out of cmcts.cpp:98-119: th_num workers of `per` searches, one after another
+    int th_num = 1, per = n;
+    if (e->threads > 1) {
+        th_num = e->threads;
+        if (n < th_num) { th_num = n; per = 1; }
+        else if (n % th_num == 0) per = n / th_num;
+        else per = n / th_num + 1;
+    }
+    for (int w = 0; w < th_num; w++) {
+        // a new worker builds a new generator (cmcts.cpp:132-133): the noise stream restarts
+        HIP_TRY(hipMemset2DAsync((char *)e->P.trees + offsetof(AzTree, noise_row), sizeof(AzTree), 0, sizeof(int),
+                                 e->n_trees, (hipStream_t)stream));
+        for (int i = 0; i < per; i++) {
+            if (e->ops->select(e->P, boards, kinds, stream)) return fail(AZ_ERR_HIP, "select launch failed");
+            if (int rc = az_net_eval(e->shape, e->n_trees, boards, kinds, d_params, front, pol, val, value, logp, stream))
+                return fail(rc, "network evaluation launch failed");
+            if (e->ops->expand_backup(e->P, value, logp, 1, stream)) return fail(AZ_ERR_HIP, "expand_backup launch failed");
+        }
+    }
+    return AZ_OK;
+}
+
+int az_simulate_net(az_engine *e, int n, const float *d_params, int front_layers, int policy_layers, int value_layers,
+                    void *stream)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    if (n < 1) return fail(AZ_ERR_BAD_SIMS, "Invalid input %d must be at least 1!", n);
+    if (!d_params || az_net_param_floats(front_layers, policy_layers, value_layers) == 0)
+        return fail(AZ_ERR_NO_PREDICTOR, "Predictor missing!");
+    if (int rc = check_noise(e)) return rc;
+    DeviceGuard g(e->device);
+    if (!e->d_stage) {
+        const StageLayout L = stage_layout(e->n_trees, e->size);
+        HIP_TRY(hipMalloc((void **)&e->d_stage, L.bytes));
+        e->device_bytes += L.bytes;
+    }
+    return simulate_net_steps(e, n, d_params, front_layers, policy_layers, value_layers, e->d_stage, stream);
+}
+
+// Errors a kernel raises for a tree.  INVALID_MOVE and NOT_DIST leave the tree
+// untouched, so reporting them clears them.  POOL_FULL, NOISE_ROWS and NO_ACTION
+// stop a search half way (visits counted along the path, no child linked, no
+// backup): such a tree stays in error -- and is skipped by every search -- until
+// az_clear / az_clear_masked resets it.
+static bool err_is_sticky(int code)
+{
+    return code == AZ_ERR_POOL_FULL || code == AZ_ERR_NOISE_ROWS || code == AZ_ERR_NO_ACTION;
+}
+
 static int sync_check_impl(az_engine *e, void *stream, int *tree_out)
 {
     DeviceGuard g(e->device);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     if (int rc = fetch_trees(e)) return rc;
-    int first = -1;
+    int first = -1, n_err = 0, n_transient = 0;
     for (int t = 0; t < e->n_trees; t++)
-        if (e->h_trees[t].err) { first = t; break; }
+        if (e->h_trees[t].err) {
+            if (first < 0) first = t;
+            n_err++;
+            if (!err_is_sticky(e->h_trees[t].err)) n_transient++;
+        }
     if (tree_out) *tree_out = first;
     if (first < 0) return AZ_OK;
     const int code = e->h_trees[first].err;
-    // clear the error words (a 4-byte strided memset)
-    HIP_TRY(hipMemset2D((char *)e->P.trees + offsetof(AzTree, err), sizeof(AzTree), 0, sizeof(int), e->n_trees));
+    if (n_transient) { // write back the error words with the transient codes cleared
+        std::vector<int> words(e->n_trees);
+        for (int t = 0; t < e->n_trees; t++) words[t] = err_is_sticky(e->h_trees[t].err) ? e->h_trees[t].err : 0;
+        HIP_TRY(hipMemcpy2D((char *)e->P.trees + offsetof(AzTree, err), sizeof(AzTree), words.data(), sizeof(int),
+                            sizeof(int), e->n_trees, hipMemcpyHostToDevice));
+    }
+    if (n_err > 1) return fail(code, "%s (tree %d; %d trees in error)", kernel_err_text(code), first, n_err);
     return fail(code, "%s (tree %d)", kernel_err_text(code), first);
 }
 
@@ -498,6 +588,16 @@ int az_sync_states(az_engine *e, void *stream, int *player, int *move_cnt, float
     return AZ_OK;
 }
 
+int az_get_errors(az_engine *e, void *stream, int *codes)
+{
+    if (!e || !codes) return fail(AZ_ERR_ARG, "null argument");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (int rc = fetch_trees(e)) return rc;
+    for (int t = 0; t < e->n_trees; t++) codes[t] = e->h_trees[t].err;
+    return AZ_OK;
+}
+
 int az_make_move(az_engine *e, const int *actions, int on_device, void *stream)
 {
     if (!e || !actions) return fail(AZ_ERR_ARG, "null argument");
@@ -512,8 +612,12 @@ int az_make_move(az_engine *e, const int *actions, int on_device, void *stream)
     if (!on_device) {
         int tree = -1;
         int rc = sync_check_impl(e, stream, &tree);
-        if (rc == AZ_ERR_INVALID_MOVE) // worded like State::make_move (state.cpp:85-86)
-            return fail(rc, "Invalid move %d (tree %d)", tree >= 0 ? actions[tree] : -1, tree);
+        // an illegal move of this call comes first (worded like State::make_move,
+        // state.cpp:85-86); h_trees still holds the error words as fetched
+        for (int t = 0; t < e->n_trees; t++)
+            if (e->h_trees[t].err == AZ_ERR_INVALID_MOVE)
+                return fail(AZ_ERR_INVALID_MOVE, "Invalid move %d (tree %d)", actions[t], t);
+        (void)tree;
         return rc;
     }
     return AZ_OK;
@@ -588,6 +692,7 @@ int az_get_counts(az_engine *e, int *counts, int *root_n)
 {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     DeviceGuard g(e->device);
+    HIP_TRY(hipDeviceSynchronize());
     if (e->ops->get_counts(e->P, e->d_counts, e->d_root_n, nullptr)) return fail(AZ_ERR_HIP, "get_counts launch failed");
     if (counts)
         HIP_TRY(hipMemcpy(counts, e->d_counts, sizeof(int) * (size_t)e->n_trees * e->size, hipMemcpyDeviceToHost));

@@ -1378,6 +1378,9 @@ __global__ __launch_bounds__(64) void k_restart(AzParams P, const int *d_opening
     const int lane = threadIdx.x;
     AzTree *T = &P.trees[tree];
     if (unif(T->winner) == -1.f) return;
+    // a tree in error keeps its error (and its finished game) until the caller
+    // has seen it and cleared the tree: a restart must not hide a failed search
+    if (uni(T->err) != 0) return;
     const size_t tbase = (size_t)tree * P.cap;
     const int n = uni(T->n_order);
     const int free_top = uni(T->free_top);

@@ -310,12 +310,13 @@ template <int S> int launch(const float *boards, const int *leaf_kind, int n, co
     if (grid > n) grid = n;
     // + the workgroup's own list of positions (at most ceil(n / grid) entries)
     const size_t lds_bytes = fixed_bytes + (size_t)((n + grid - 1) / grid) * sizeof(int);
-    static size_t configured = 0; // largest size the kernel has been opened up to
-    if (lds_bytes > configured) {
+    // largest size the kernel has been opened up to, per device (the attribute is per device)
+    static size_t configured[64] = {};
+    if (dev < 0 || dev >= 64 || lds_bytes > configured[dev]) {
         if (hipFuncSetAttribute((const void *)k_net_eval<S>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes) != hipSuccess)
             return AZ_ERR_HIP;
-        configured = lds_bytes;
+        if (dev >= 0 && dev < 64) configured[dev] = lds_bytes;
     }
     hipLaunchKernelGGL(k_net_eval<S>, dim3(grid), dim3(G::NTHR), lds_bytes, st, boards, leaf_kind, n, prm, front, pol, val, value_out,
                        logp_out);

@@ -54,6 +54,8 @@ SYMBOLS = [
     ("az_begin_simulate", _i, [_vp, _vp]),
     ("az_select", _i, [_vp, _vp, _vp, _vp]),
     ("az_expand_backup", _i, [_vp, _vp, _vp, _i, _vp]),
+    ("az_simulate_net", _i, [_vp, _i, _vp, _i, _i, _i, _vp]),
+    ("az_get_errors", _i, [_vp, _vp, _vp]),
     ("az_make_move", _i, [_vp, _vp, _i, _vp]),
     ("az_make_movexy", _i, [_vp, _i, _i, _i]),
     ("az_select_greedy", _i, [_vp, _vp, _vp]),
@@ -235,6 +237,20 @@ class Engine:
 
     def expand_backup(self, d_value, d_prior, prior_is_log, stream=None):
         self._check(self.L.az_expand_backup(self.h, _ptr(d_value), _ptr(d_prior), int(prior_is_log), stream))
+
+    def simulate_net(self, n, d_params, layers, stream=None, sync=True):
+        """n searches per active tree with the fused network kernel as the predictor,
+        all steps queued by one call (d_params: device pointer of the packed
+        parameters, layers = (front, policy, value) counts)."""
+        self._check(self.L.az_simulate_net(self.h, int(n), _ptr(d_params), int(layers[0]), int(layers[1]),
+                                           int(layers[2]), stream))
+        if sync:
+            self.sync_check(stream)
+
+    def get_errors(self, stream=None):
+        codes = np.zeros(self.n_trees, np.int32)
+        self._check(self.L.az_get_errors(self.h, stream, _ptr(codes)))
+        return codes
 
     def make_move(self, actions, stream=None):
         actions = np.ascontiguousarray(actions, np.int32)

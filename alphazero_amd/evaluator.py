@@ -75,6 +75,9 @@ class FusedNetEvaluator:
         packed, self.layers = self.pack(state)
         assert packed.numel() == self.L.az_net_param_floats(*self.layers)
         self.params = packed.to(self.device)
+        # (front, policy, value) layer counts: marks the evaluator as one the engine can
+        # drive by itself (az_simulate_net), without a Python round trip per search step
+        self.fused_layers = self.layers
 
     @staticmethod
     def supports(state):

@@ -80,6 +80,13 @@ class TreeBatch:
                 per = n // th_num + 1
         self._ensure_noise(per)
         stream = torch.cuda.current_stream(self.dev).cuda_stream
+        if getattr(self.evaluator, "fused_layers", None) is not None:
+            # the library's own network kernel: one call queues every step of the search
+            try:
+                eng.simulate_net(n, self.evaluator.params.data_ptr(), self.evaluator.fused_layers, stream)
+            except _E.EngineError as e:
+                raise RuntimeError(str(e)) from None
+            return
         with torch.no_grad():
             for _ in range(th_num):
                 eng.begin_simulate(stream)

@@ -6,6 +6,10 @@
  * GPU.  Every entry point takes plain pointers and sizes; pointers named
  * `d_*` are device addresses on the engine's GPU, all others are host memory.
  * `stream` arguments are a hipStream_t passed as void* (NULL = default stream).
+ * Entry points WITHOUT a stream argument that touch device state (setters of
+ * per-tree state, az_clear*, the az_get_* read-backs) first wait for all work
+ * queued on the device (hipDeviceSynchronize), so they are ordered after
+ * searches and moves issued on any stream.
  *
  * Each function cites the reference interface it replaces
  * (paths relative to the reference repository root).
@@ -158,6 +162,17 @@ int az_select(az_engine *e, float *d_boards, int *d_leaf_kind, void *stream);
 int az_expand_backup(az_engine *e, const float *d_value, const float *d_prior, int prior_is_log,
                      void *stream);
 
+/* Cmcts::simulate (cmcts.cpp:83-125) with the reference network as the predictor
+ * (the torch::jit module of cmcts.cpp:137,217): n searches on every active tree,
+ * each search step = az_select, az_net_eval on the step's leaves, az_expand_backup,
+ * all queued on `stream` by this one call (the loop of cmcts.cpp:151-154 without a
+ * return to the caller per search; thread fan-out as in az_simulate_fused).
+ * d_params / *_layers: as az_net_eval takes them.  The step's leaf boards, codes,
+ * values and log-priors live in a buffer the engine allocates on first use.
+ * Asynchronous; errors surface at az_sync_check. */
+int az_simulate_net(az_engine *e, int n, const float *d_params, int front_layers, int policy_layers,
+                    int value_layers, void *stream);
+
 /* Cmcts::make_move (cmcts.cpp:284-294) on every tree with action >= 0
  * (action < 0 = leave the tree alone).  `actions` is a host array unless
  * on_device.  Illegal moves change nothing; with a host array the call fails
@@ -225,9 +240,18 @@ int az_reset_stats(az_engine *e);
 int az_get_pool_usage(az_engine *e, int tree, int *used, int *max_used);
 
 /* waits for the engine's outstanding work on `stream` and reports the first
- * per-tree error raised inside a kernel (AZ_ERR_POOL_FULL, AZ_ERR_NO_ACTION,
- * AZ_ERR_NOISE_ROWS, AZ_ERR_INVALID_MOVE), clearing it. */
+ * per-tree error raised inside a kernel, with the number of trees in error.
+ * AZ_ERR_INVALID_MOVE and AZ_ERR_NOT_DIST leave their tree untouched and are
+ * cleared by the report.  AZ_ERR_POOL_FULL, AZ_ERR_NOISE_ROWS and
+ * AZ_ERR_NO_ACTION stop a search half way (the reference throws out of
+ * Cmcts::search at the same points, cmcts.cpp:216-240, leaving its tree in the
+ * same state): the tree stays in error, is skipped by every later search and is
+ * reported by every later check until az_clear / az_clear_masked resets it
+ * (az_restart_finished leaves such a tree alone). */
 int az_sync_check(az_engine *e, void *stream);
+/* the pending error code of every tree after the work on `stream` (host int
+ * [n_trees], 0 = none); clears nothing */
+int az_get_errors(az_engine *e, void *stream, int *codes);
 /* az_sync_check followed by az_get_states from one device-to-host copy: what a
  * caller does after every move (`mcts.winner != -1`, src/self_play.py:169,185;
  * src/eval.py:194,204).  Any of the three output arrays may be NULL. */

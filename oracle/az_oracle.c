@@ -725,14 +725,21 @@ int azo_select_arrays(int size, const long *n, const double *w, const double *p,
 }
 
 /* ------------------------------------------------------------------ */
-/* CPU baseline: independent single-thread games, one per host thread   */
+/* CPU baseline legs (bench.py): the same game loop the GPU bench steps  */
+/* through -- two-ply opening, then per ply simulate(sims) + greedy move,*/
+/* finished games restarted from their opening.  The first `skip` plies  */
+/* of every game are played but not timed, so the timed plies are the    */
+/* ones the GPU leg times after its warm-up steps.                       */
 /* ------------------------------------------------------------------ */
 typedef struct {
-    int shape, games, plies, sims;
+    int shape, games, skip, plies, sims, tree_threads;
     double cpuct;
     const azo_evaluator *ev;
-    int next_game; /* atomic */
-    long long total_sims; /* atomic */
+    int next_game;        /* atomic */
+    long long total_sims; /* atomic: searches inside timed plies (as counted by the trees) */
+    double rate_sum;      /* sum over workers of timed searches / timed seconds (under mu) */
+    double secs_max;      /* longest timed span of a worker (under mu) */
+    pthread_mutex_t mu;
 } az_bl_job;
 
 void azo_opening(int size, int g, int *a0, int *a1)
@@ -749,9 +756,18 @@ static void bl_open(azo_tree *t, int g)
     azo_make_move(t, a1);
 }
 
+static double bl_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 static void *bl_main(void *arg)
 {
     az_bl_job *job = (az_bl_job *)arg;
+    double secs = 0.;
+    long long sims = 0;
     for (;;) {
         int g = __atomic_fetch_add(&job->next_game, 1, __ATOMIC_RELAXED);
         if (g >= job->games)
@@ -759,12 +775,15 @@ static void *bl_main(void *arg)
         azo_tree *t = azo_create(job->shape, 1.0, job->cpuct);
         azo_set_alpha_default(t);
         azo_set_eps(t, 0.0);
+        azo_set_threads(t, job->tree_threads);
         bl_open(t, g);
         long *counts = (long *)malloc(sizeof(long) * t->size);
-        for (int ply = 0; ply < job->plies; ply++) {
+        for (int ply = 0; ply < job->skip + job->plies; ply++) {
+            const int timed = ply >= job->skip;
+            const long long before = t->sims;
+            const double t0 = timed ? bl_now() : 0.;
             if (azo_simulate(t, job->sims, job->ev, NULL, 0))
                 break;
-            __atomic_add_fetch(&job->total_sims, job->sims, __ATOMIC_RELAXED);
             azo_root_counts(t, counts);
             int best = 0;
             for (int i = 1; i < t->size; i++)
@@ -775,28 +794,50 @@ static void *bl_main(void *arg)
                 azo_clear(t);
                 bl_open(t, g);
             }
+            if (timed) {
+                secs += bl_now() - t0;
+                sims += t->sims - before; /* the fan-out may overshoot the request (cmcts.cpp:106-107) */
+            }
         }
         free(counts);
         azo_destroy(t);
     }
+    __atomic_add_fetch(&job->total_sims, sims, __ATOMIC_RELAXED);
+    pthread_mutex_lock(&job->mu);
+    if (secs > 0.)
+        job->rate_sum += (double)sims / secs;
+    if (secs > job->secs_max)
+        job->secs_max = secs;
+    pthread_mutex_unlock(&job->mu);
     return NULL;
 }
 
-long long azo_baseline_games(int shape, int games, int threads, int plies, int sims,
-                             double cpuct, const azo_evaluator *ev, double *secs)
+/* `workers` host threads play `games` games between them, each game on a tree of
+ * its own searched with `tree_threads` threads (0/1 = the sequential worker of
+ * cmcts.cpp:120-122; > 1 = the shared-tree fan-out of cmcts.cpp:98-119).
+ * Returns the searches done inside timed plies; *rate = sum over the workers of
+ * their own searches per second of timed plies (the workers run side by side for
+ * the whole call), *secs = the longest worker's timed span. */
+long long azo_baseline_run(int shape, int games, int workers, int tree_threads, int skip, int plies,
+                           int sims, double cpuct, const azo_evaluator *ev, double *rate, double *secs)
 {
-    az_bl_job job = {shape, games, plies, sims, cpuct, ev, 0, 0};
-    if (threads < 1)
-        threads = 1;
-    struct timespec t0, t1;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
-    for (int i = 0; i < threads; i++)
-        pthread_create(&th[i], NULL, bl_main, &job);
-    for (int i = 0; i < threads; i++)
+    az_bl_job job;
+    memset(&job, 0, sizeof job);
+    job.shape = shape; job.games = games; job.skip = skip; job.plies = plies; job.sims = sims;
+    job.tree_threads = tree_threads; job.cpuct = cpuct; job.ev = ev;
+    pthread_mutex_init(&job.mu, NULL);
+    if (workers < 1)
+        workers = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * workers);
+    int started = 0;
+    for (int i = 0; i < workers; i++)
+        if (pthread_create(&th[i], NULL, bl_main, &job) == 0)
+            th[started++] = th[i];
+    for (int i = 0; i < started; i++)
         pthread_join(th[i], NULL);
-    clock_gettime(CLOCK_MONOTONIC, &t1);
     free(th);
-    *secs = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    pthread_mutex_destroy(&job.mu);
+    if (rate) *rate = job.rate_sum;
+    if (secs) *secs = job.secs_max;
     return job.total_sims;
 }

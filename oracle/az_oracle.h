@@ -133,11 +133,14 @@ void azo_hash_eval(int shape, unsigned long long seed, const signed char *board,
 /* distinct two-ply opening of game g (shared by the baseline and the GPU bench) */
 void azo_opening(int size, int g, int *a0, int *a1);
 
-/* CPU baseline workload: `games` independent single-thread trees, one per
- * thread up to `threads` at a time, each playing `plies` greedy moves of
- * `sims` simulations; returns total simulations run, wall seconds in *secs. */
-long long azo_baseline_games(int shape, int games, int threads, int plies, int sims,
-                             double cpuct, const azo_evaluator *ev, double *secs);
+/* CPU baseline legs for bench.py: `workers` host threads play `games` games
+ * (two-ply opening, then per ply simulate(sims) + greedy move, finished games
+ * restarted), each tree searched with `tree_threads` threads (<= 1: sequential;
+ * > 1: the shared-tree fan-out of cmcts.cpp:98-119).  The first `skip` plies of a
+ * game are untimed.  Returns the timed searches; *rate = sum over workers of
+ * searches per second, *secs = longest worker's timed span. */
+long long azo_baseline_run(int shape, int games, int workers, int tree_threads, int skip, int plies,
+                           int sims, double cpuct, const azo_evaluator *ev, double *rate, double *secs);
 
 #ifdef __cplusplus
 }

@@ -97,9 +97,9 @@ def lib():
         L.azo_hash_eval.restype = None
         L.azo_opening.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.azo_opening.restype = None
-        L.azo_baseline_games.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
-                                         C.POINTER(Evaluator), C.POINTER(C.c_double)]
-        L.azo_baseline_games.restype = C.c_longlong
+        L.azo_baseline_run.argtypes = [C.c_int] * 7 + [C.c_double, C.POINTER(Evaluator), C.POINTER(C.c_double),
+                                                      C.POINTER(C.c_double)]
+        L.azo_baseline_run.restype = C.c_longlong
         _lib = L
     return _lib
 
@@ -279,7 +279,9 @@ def opening(size, g):
     return a0.value, a1.value
 
 
-def baseline_games(shape, games, threads, plies, sims, cpuct, ev):
-    secs = C.c_double()
-    total = lib().azo_baseline_games(shape, games, threads, plies, sims, cpuct, C.byref(ev), C.byref(secs))
-    return total, secs.value
+def baseline_run(shape, games, workers, tree_threads, skip, plies, sims, cpuct, ev):
+    """-> (timed searches, searches per second summed over the workers, longest worker's timed seconds)"""
+    rate, secs = C.c_double(), C.c_double()
+    total = lib().azo_baseline_run(shape, games, workers, tree_threads, skip, plies, sims, cpuct, C.byref(ev),
+                                   C.byref(rate), C.byref(secs))
+    return total, rate.value, secs.value

@@ -79,8 +79,11 @@ def test_self_play_sampled_moves_single_game():
     b1.close()
 
 
+@pytest.mark.parametrize("eps", [0.0, 0.25])
 @pytest.mark.parametrize("driver", ["host", "device"])
-def test_eval_games_match_reference_loop(driver):
+def test_eval_games_match_reference_loop(driver, eps):
+    """Arena of two different networks; with eps = 0.25 the Dirichlet noise stays on
+    as in the reference's arena (src/eval.py:86,92), fed from one fixture table."""
     from alphazero_amd import selfplay as sp
 
     S, size, G = 7, 49, 6
@@ -97,8 +100,13 @@ def test_eval_games_match_reference_loop(driver):
         v, p = exact_eval_numpy(b)
         return -v, p[::-1].copy()
 
-    best = sp.TreeBatch(G, S, ExactTorchEvaluator(), cpuct=4.0, eps=0.0, nodes_per_tree=600)
-    latest = sp.TreeBatch(G, S, Shifted(), cpuct=2.0, eps=0.0, nodes_per_tree=600)
+    best = sp.TreeBatch(G, S, ExactTorchEvaluator(), cpuct=4.0, eps=eps, nodes_per_tree=600)
+    latest = sp.TreeBatch(G, S, Shifted(), cpuct=2.0, eps=eps, nodes_per_tree=600)
+    noise = None
+    if eps > 0:
+        noise = _noise(max(sims_b, sims_l) + 2, size, best.eng.get_alpha(), 17)
+        best.set_noise_table(noise)
+        latest.set_noise_table(noise)
     for ply in range(2):
         act = np.array([O.opening(size, g * 3 + 2)[ply] for g in range(G)], np.int32)
         best.make_move(act)
@@ -110,14 +118,15 @@ def test_eval_games_match_reference_loop(driver):
     for g in range(G):
         tb, tl = O.OracleTree(S, cpuct=4.0), O.OracleTree(S, cpuct=2.0)
         for t in (tb, tl):
-            t.set_eps(0.0)
+            t.set_alpha_default()
+            t.set_eps(eps)
             for ply in range(2):
                 t.make_move(O.opening(size, g * 3 + 2)[ply])
         first_player = tb.player
         if g % 2 == 0:
-            oracle_eval_game(tb, sims_b, ev_b, tl, sims_l, ev_l)
+            oracle_eval_game(tb, sims_b, ev_b, tl, sims_l, ev_l, noise)
         else:
-            oracle_eval_game(tl, sims_l, ev_l, tb, sims_b, ev_b)
+            oracle_eval_game(tl, sims_l, ev_l, tb, sims_b, ev_b, noise)
         w = tb.winner
         assert float(best.winners()[g]) == w
         if w == first_player:

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,17 @@ const AzShapeOps *find_ops(int shape)
 }
 
 } // namespace
+
+// Step staging of az_simulate_net_noalloc: one fixed buffer per GPU, part of the
+// library's device image (every GPU the library runs on holds it until the
+// process ends).  Host code never uses the array's name as an address: the
+// per-device address is looked up once per device (resolve_scratch, from
+// az_create) and passed to the kernels like any other buffer.
+#define AZ_NOALLOC_SCRATCH_BYTES (5u << 20)
+#define AZ_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[AZ_NOALLOC_SCRATCH_BYTES];
+static char *g_scratch_ptr[AZ_MAX_DEVICES] = {};
+static std::mutex g_scratch_mu;
 
 struct az_engine {
     int device = 0;
@@ -104,6 +116,18 @@ int fetch_trees(az_engine *e)
     return AZ_OK;
 }
 
+// address of `scratch` on `device`, which must be the current device
+int resolve_scratch(int device)
+{
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[device]) return AZ_OK;
+    void *ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return fail(AZ_ERR_HIP, "hipGetSymbolAddress returned a null address");
+    g_scratch_ptr[device] = static_cast<char *>(ptr);
+    return AZ_OK;
+}
+
 int check_tree(const az_engine *e, int tree)
 {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
@@ -150,12 +174,14 @@ int az_create(az_engine **out, int device, int n_trees, int shape, int nodes_per
                     (size_t)(0xFFFFFFFFull / ((size_t)ops->sp * 24)));
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
-    if (device < 0 || device >= ndev) return fail(AZ_ERR_ARG, "device %d not present (%d visible)", device, ndev);
+    if (device < 0 || device >= ndev || device >= AZ_MAX_DEVICES)
+        return fail(AZ_ERR_ARG, "device %d not present (%d visible)", device, ndev);
 
     az_engine *e = new az_engine();
     e->device = device;
     DeviceGuard g(device);
     if (!g.ok) { delete e; return fail(AZ_ERR_HIP, "hipSetDevice(%d) failed", device); }
+    if (int rc = resolve_scratch(device)) { delete e; return rc; }
     e->n_trees = n_trees;
     e->shape = shape;
     e->size = shape * shape;
@@ -533,6 +559,29 @@ int az_simulate_net(az_engine *e, int n, const float *d_params, int front_layers
         e->device_bytes += L.bytes;
     }
     return simulate_net_steps(e, n, d_params, front_layers, policy_layers, value_layers, e->d_stage, stream);
+}
+
+int az_simulate_net_noalloc(az_engine *e, int n, const float *d_params, int front_layers, int policy_layers,
+                            int value_layers, void *stream)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    if (n < 1) return fail(AZ_ERR_BAD_SIMS, "Invalid input %d must be at least 1!", n);
+    if (!d_params || az_net_param_floats(front_layers, policy_layers, value_layers) == 0)
+        return fail(AZ_ERR_NO_PREDICTOR, "Predictor missing!");
+    if (int rc = check_noise(e)) return rc;
+    const StageLayout L = stage_layout(e->n_trees, e->size);
+    if (L.bytes > AZ_NOALLOC_SCRATCH_BYTES) {
+        const size_t per_tree = (size_t)(3 * e->size + 2) * 4;
+        return fail(AZ_ERR_ARG,
+                    "az_simulate_net_noalloc: %d trees of %dx%d need %zu bytes of step staging, the fixed buffer "
+                    "holds %u (about %zu trees of this shape); use az_simulate_net",
+                    e->n_trees, e->shape, e->shape, L.bytes, AZ_NOALLOC_SCRATCH_BYTES,
+                    (size_t)(AZ_NOALLOC_SCRATCH_BYTES - 1024) / per_tree);
+    }
+    DeviceGuard g(e->device);
+    char *ptr = g_scratch_ptr[e->device]; // resolved by az_create on this device
+    if (!ptr) return fail(AZ_ERR_STATE, "the fixed staging buffer was not resolved on device %d", e->device);
+    return simulate_net_steps(e, n, d_params, front_layers, policy_layers, value_layers, ptr, stream);
 }
 
 // Errors a kernel raises for a tree.  INVALID_MOVE and NOT_DIST leave the tree

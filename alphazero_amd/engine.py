@@ -55,6 +55,7 @@ SYMBOLS = [
     ("az_select", _i, [_vp, _vp, _vp, _vp]),
     ("az_expand_backup", _i, [_vp, _vp, _vp, _i, _vp]),
     ("az_simulate_net", _i, [_vp, _i, _vp, _i, _i, _i, _vp]),
+    ("az_simulate_net_noalloc", _i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     ("az_get_errors", _i, [_vp, _vp, _vp]),
     ("az_make_move", _i, [_vp, _vp, _i, _vp]),
     ("az_make_movexy", _i, [_vp, _i, _i, _i]),
@@ -244,6 +245,13 @@ class Engine:
         parameters, layers = (front, policy, value) counts)."""
         self._check(self.L.az_simulate_net(self.h, int(n), _ptr(d_params), int(layers[0]), int(layers[1]),
                                            int(layers[2]), stream))
+        if sync:
+            self.sync_check(stream)
+
+    def simulate_net_noalloc(self, n, d_params, layers, stream=None, sync=True):
+        """simulate_net with the step staging in the library's fixed per-GPU buffer (no allocation)."""
+        self._check(self.L.az_simulate_net_noalloc(self.h, int(n), _ptr(d_params), int(layers[0]), int(layers[1]),
+                                                   int(layers[2]), stream))
         if sync:
             self.sync_check(stream)
 

@@ -172,6 +172,17 @@ int az_expand_backup(az_engine *e, const float *d_value, const float *d_prior, i
  * Asynchronous; errors surface at az_sync_check. */
 int az_simulate_net(az_engine *e, int n, const float *d_params, int front_layers, int policy_layers,
                     int value_layers, void *stream);
+/* az_simulate_net for callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc): same
+ * arguments, same kernels, same results, but the step staging lives in a fixed
+ * 5 MiB buffer inside the library's device image instead of a buffer allocated
+ * on first use, and the call makes no hipMalloc / hipFree.  No counterpart in the
+ * reference.  Fails with AZ_ERR_ARG when n_trees * (3 * SIZE + 2) * 4 bytes (plus
+ * alignment) exceed the buffer (1935 trees at 15x15, 1090 at 20x20 fit).  All
+ * engines on one GPU share the buffer: two such calls whose work overlaps in time
+ * on one GPU (different streams) race; calls on one stream are safe. */
+int az_simulate_net_noalloc(az_engine *e, int n, const float *d_params, int front_layers, int policy_layers,
+                            int value_layers, void *stream);
 
 /* Cmcts::make_move (cmcts.cpp:284-294) on every tree with action >= 0
  * (action < 0 = leave the tree alone).  `actions` is a host array unless

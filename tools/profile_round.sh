@@ -1,14 +1,23 @@
 #!/bin/bash
-# Profiles `bench.py --no-cpu-baseline` on the GPU box: one kernel-trace pass and
-# separate counter passes (never combined with a trace domain), then condenses
-# them into profiles/<tag>_*.  Usage: tools/profile_round.sh <tag>
+# Profiles a bench.py run on the GPU box: one kernel-trace pass and separate
+# counter passes (never combined with a trace domain), then condenses them into
+# profiles/<tag>_*.
+# Usage: tools/profile_round.sh <tag> [<workload>]
+#   no workload: the headline run (traffic figures go to the top level of profiles/traffic.json)
+#   workload:    a name `bench.py --only` takes, e.g. hash_8192_15 (figures stored under that key)
 set -e
-tag=${1:-r01}
+tag=${1:-r02}
+wl=${2:-}
 cd "$(dirname "$0")/.."
 out=gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-B="python3 bench.py --no-cpu-baseline --steps 6 --warmup 2"
+if [ -n "$wl" ]; then
+  B="python3 bench.py --only $wl"
+  export TRAFFIC_KEY="$wl"
+else
+  B="python3 bench.py --no-cpu-baseline --no-secondary --steps 6 --warmup 2"
+fi
 timeout -k 10 170 rocprofv3 --kernel-trace --stats -d "$out/stats" -o s --output-format csv -- $B > "$out/stats.log" 2>&1
 echo stats done
 timeout -s KILL 170 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY -d "$out/pmc_sq" -o p --output-format csv -- $B > "$out/pmc_sq.log" 2>&1

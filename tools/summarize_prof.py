@@ -46,11 +46,23 @@ def main():
         if "hbm_bytes_per_launch" in o:
             print(k, "hbm bytes/launch", o["hbm_bytes_per_launch"])
             if "k_simulate_fused" in k:
-                # the figure bench.py reports as roofline.traffic
-                with open(os.path.join(root, "traffic.json"), "w") as f:
-                    json.dump({"kernel": k, "source": f"{tag}_pmc.json",
-                               "hbm_read_bytes": o["hbm_read_bytes"], "hbm_write_bytes": o["hbm_write_bytes"],
-                               "hbm_bytes_per_launch": o["hbm_bytes_per_launch"]}, f, indent=1)
+                # the figure bench.py reports as roofline.traffic: the headline run's at the top
+                # level, a secondary workload's (TRAFFIC_KEY = its bench.py name) under its name
+                path = os.path.join(root, "traffic.json")
+                try:
+                    cur = json.load(open(path))
+                except Exception:
+                    cur = {}
+                rec = {"kernel": k, "source": f"{tag}_pmc.json",
+                       "hbm_read_bytes": o["hbm_read_bytes"], "hbm_write_bytes": o["hbm_write_bytes"],
+                       "hbm_bytes_per_launch": o["hbm_bytes_per_launch"]}
+                key = os.environ.get("TRAFFIC_KEY")
+                if key:
+                    cur[key] = rec
+                else:
+                    cur.update(rec)
+                with open(path, "w") as f:
+                    json.dump(cur, f, indent=1)
 
 
 if __name__ == "__main__":

@@ -515,28 +515,63 @@ def promote(wins_best, wins_latest, threshold=0.6):
 
 
 # ---------------------------------------------------------------- multi-GPU
-def gather_samples(samples, group=None):
-    """All ranks' sample arrays on every rank (one all_gather; RCCL over xGMI with
-    the nccl backend, gloo on CPU).  `samples`: structured array of this rank."""
+def gather_samples(samples, dst=0, group=None, all_ranks=False, chunk_bytes=64 << 20):
+    """Every rank's sample records in rank order, on rank `dst` (the other ranks get an
+    empty array, or the whole set too with all_ranks=True).  Point-to-point transfers
+    in pieces of at most `chunk_bytes` through ONE staging buffer of that size per
+    rank (device memory with the nccl backend = RCCL over xGMI, host memory with
+    gloo), so the exchange needs no world x payload buffers: a 65,536-game batch of
+    20x20 records is about 19 GB, which only the host of `dst` ever holds whole.
+    `samples`: structured array of this rank (any length, also 0)."""
     import torch
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()):
         return samples
-    world = dist.get_world_size(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    nccl = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
     raw = np.frombuffer(samples.tobytes(), np.uint8)
     n = torch.tensor([raw.size], dtype=torch.int64, device=dev)
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
+    dist.all_gather(sizes, n, group=group)  # 8 bytes per rank
     sizes = [int(s.item()) for s in sizes]
-    cap = max(sizes) if sizes else 0
-    buf = torch.zeros(max(cap, 1), dtype=torch.uint8, device=dev)
-    buf[: raw.size] = torch.from_numpy(raw.copy()).to(dev)
-    parts = [torch.zeros(max(cap, 1), dtype=torch.uint8, device=dev) for _ in range(world)]
-    dist.all_gather(parts, buf, group=group)
-    chunks = [np.frombuffer(p[:s].cpu().numpy().tobytes(), dtype=samples.dtype) for p, s in zip(parts, sizes)]
-    return np.concatenate(chunks) if chunks else samples
+    chunk = max(1, int(chunk_bytes))
+    stage = torch.empty(min(chunk, max(sum(sizes) if all_ranks else max(sizes), 1)), dtype=torch.uint8, device=dev)
+    # dist.send/recv address ranks of the default group
+    to_global = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+    if rank == dst:
+        total = np.empty(sum(sizes), np.uint8)
+        at = 0
+        for src in range(world):
+            for off in range(0, sizes[src], chunk):
+                k = min(chunk, sizes[src] - off)
+                if src == dst:
+                    total[at:at + k] = raw[off:off + k]
+                else:
+                    dist.recv(stage[:k], src=to_global(src), group=group)
+                    total[at:at + k] = stage[:k].cpu().numpy()
+                at += k
+    else:
+        total = None
+        for off in range(0, sizes[rank], chunk):
+            k = min(chunk, sizes[rank] - off)
+            stage[:k].copy_(torch.from_numpy(raw[off:off + k].copy()))
+            dist.send(stage[:k], dst=to_global(dst), group=group)
+    if all_ranks:
+        n_total = sum(sizes)
+        if total is None:
+            total = np.empty(n_total, np.uint8)
+        for off in range(0, n_total, chunk):
+            k = min(chunk, n_total - off)
+            if rank == dst:
+                stage[:k].copy_(torch.from_numpy(total[off:off + k].copy()))
+            dist.broadcast(stage[:k], src=to_global(dst), group=group)
+            if rank != dst:
+                total[off:off + k] = stage[:k].cpu().numpy()
+    if total is None:
+        return np.zeros(0, samples.dtype)
+    return np.frombuffer(total.tobytes(), dtype=samples.dtype)
 
 
 def broadcast_parameters(tensors, src=0, group=None):

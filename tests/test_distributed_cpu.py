@@ -39,7 +39,12 @@ def _worker(rank, world, port, out_dir):
         a["board"][:, 0, g % 5, 0] = 1
         recs.append(a)
     mine = np.concatenate(recs) if recs else np.zeros(0, dt)
-    everything = sp.gather_samples(mine)
+    # a piece size far below one rank's payload (a record is 304 bytes), and not a divisor of it
+    everything = sp.gather_samples(mine, chunk_bytes=1000)
+    np.save(os.path.join(out_dir, f"all_everywhere_{rank}.npy"), sp.gather_samples(mine, all_ranks=True, chunk_bytes=777))
+    # uneven and empty shards: rank 1 has nothing to send, rank 0 is not the destination
+    lop = mine[:5] if rank == 0 else mine[:0]
+    np.save(os.path.join(out_dir, f"lop_{rank}.npy"), sp.gather_samples(lop, dst=1, chunk_bytes=100))
     counters = sp.reduce_counters([len(mine), hi - lo, rank])
     # evaluator replicas start from rank 0's weights
     import torch
@@ -63,7 +68,13 @@ def test_two_rank_gather_and_reduce(tmp_path):
     a0 = np.load(tmp_path / "all_0.npy")
     a1 = np.load(tmp_path / "all_1.npy")
     assert a0.dtype.names == ("board", "pi", "r")
-    assert np.array_equal(a0["r"], a1["r"]) and np.array_equal(a0["pi"], a1["pi"])
+    assert len(a1) == 0 and a1.dtype == a0.dtype  # gathered on rank 0 only
+    for r in (0, 1):  # all_ranks=True: every rank holds the same, complete set
+        e = np.load(tmp_path / f"all_everywhere_{r}.npy")
+        assert np.array_equal(e["r"], a0["r"]) and np.array_equal(e["pi"], a0["pi"]) and np.array_equal(e["board"], a0["board"])
+    l0, l1 = np.load(tmp_path / "lop_0.npy"), np.load(tmp_path / "lop_1.npy")
+    assert len(l0) == 0 and len(l1) == 5 and np.array_equal(l1["r"], a0["r"][:5]) and np.array_equal(l1["pi"], a0["pi"][:5])
+    assert [int(b[0, g % 5, 0]) for b, g in zip(a0["board"], a0["r"].astype(int))] == [1] * len(a0)
     # 7 games, game g has g+1 records, rank order preserved
     assert len(a0) == sum(range(1, 8))
     assert a0["r"].tolist() == [float(g) for g in range(7) for _ in range(g + 1)]

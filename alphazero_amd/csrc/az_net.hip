@@ -3,16 +3,23 @@
 // batch 1 at mcts/src/cmcts.cpp:206-231) for ALL leaf positions of a search
 // step in one launch, inference mode (batch-norm folded to scale/shift).
 //
-// gfx950 design: a workgroup of four wavefronts owns one position at a time.
-// The 16-channel activations of the whole net stay in LDS (three planes-major
-// buffers with a zero halo), so HBM sees only the input planes and the outputs.
+// gfx950 design.  A small workgroup (two wavefronts at 15x15) owns one position
+// at a time and four such workgroups share a CU, so every SIMD holds two
+// wavefronts of different positions.  The 16-channel activations stay in LDS in
+// TWO plane-major buffers with a zero halo: the trunk and the later layers of a
+// branch run IN PLACE (all tiles of a layer are accumulated in registers, a
+// barrier, then the results overwrite the input), which is what lets four
+// positions fit into the 160 KB of a CU.  HBM sees only the input planes and the
+// outputs.
 // Every 3x3 convolution is an implicit GEMM on the f32-input matrix cores
-// (v_mfma_f32_16x16x4_f32: exact f32 products, f32 accumulate): M = 16 pixels of
-// one board row (boards wider than 16: 16 consecutive pixels in row-major order,
-// see Geo::FLAT), N = the 16 output channels, K = 4 input channels of one tap;
-// each wavefront carries four independent accumulators (four rows), which is
-// what the 40-cycle dependent latency of that instruction needs.  The 1-channel
-// heads run on the VALU.
+// (v_mfma_f32_16x16x4_f32: exact f32 products, f32 accumulate): M = 16 pixels
+// that are consecutive in row-major order over the whole board (tiles cross row
+// ends, so 15x15 = 14 full tiles + one pixel, which a wavefront adds on the
+// vector ALU with the weights it already holds), N = the 16 output channels,
+// K = 4 input channels of one tap.  A wavefront carries all of its tiles (7 at
+// 15x15) as independent accumulators.  The policy head is a 1x1 product on the
+// matrix cores too (16 channels -> 9 per-tap partial planes) followed by a 9-term
+// gather; the value head is summed from the registers of the last value layer.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -20,9 +27,6 @@
 
 namespace {
 
-#ifndef AZ_NET_FORCE_NW
-#define AZ_NET_FORCE_NW 0
-#endif
 constexpr int CH = 16;  // conv channels of the reference configuration (config.py:15)
 constexpr int CIN = 2;  // input planes (config.py:12)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -31,28 +35,29 @@ template <int S> struct Geo {
     static constexpr int SIZE = S * S;
     static constexpr int ROW = S + 2;               // one halo column on each side
     static constexpr int PLANE = ROW * ROW;
-    static constexpr int TPR = (S + 15) / 16;       // 16-pixel tiles per board row
-    // Tiles of one row each keep every operand read inside a row (fewer LDS bank
-    // conflicts: 16 % faster at 15x15), but a row of 17..20 pixels needs two tiles,
-    // the second nearly empty.  There the tiles run over the board in row-major
-    // order instead and cross row ends (25 instead of 40 tiles at 20x20, two rounds
-    // of the four wavefronts instead of three: 19 % faster).
-    static constexpr int NT_ROW = S * TPR, NT_FLAT = (SIZE + 15) / 16;
-    static constexpr bool FLAT = (NT_FLAT + 15) / 16 < (NT_ROW + 15) / 16;
-    static constexpr int NT = FLAT ? NT_FLAT : NT_ROW; // tiles per plane
-    // plane stride: room for the over-reads of the padded tile lanes, and odd (= 1
-    // mod 32) so the epilogue's writes, whose lanes step by one PLANE per output
-    // channel, spread over all LDS banks (measured 5 % faster than = 16 mod 32,
-    // which favours the operand reads)
-    static constexpr int PS = ((PLANE + 16 * TPR + 31) / 32) * 32 + 1;
-    // Wavefronts per workgroup (= per position).  Two workgroups of four share a CU
-    // while three activation buffers fit twice into its 160 KB of LDS; on the
-    // widest boards only one workgroup fits, which then runs eight wavefronts so
-    // that every SIMD still holds two.
-    static constexpr int NW = (AZ_NET_FORCE_NW != 0) ? AZ_NET_FORCE_NW : (2 * 3 * CH * PS * 4 > 150 * 1024 ? 8 : 4);
-    static constexpr int TPW = 16 / NW;  // tiles (accumulators) per wavefront and round
+    // plane stride: odd, so the epilogue's writes (lanes step by one plane per output
+    // channel) spread over all LDS banks
+    static constexpr int PS = PLANE | 1;
+    // a board of 16k + 1 pixels: the last pixel is computed on the vector ALU
+    static constexpr bool CORNER = SIZE % 16 == 1;
+    static constexpr int NT = CORNER ? SIZE / 16 : (SIZE + 15) / 16; // 16-pixel tiles
+    static constexpr int BUF = CH * PS;             // floats of one activation buffer
+    static constexpr int FIXED_BYTES = (2 * BUF + SIZE + 16) * 4;
+    // workgroups per CU by LDS, and wavefronts per workgroup so that a CU holds about
+    // eight wavefronts (two per SIMD)
+    static constexpr int WGS = (158 * 1024) / FIXED_BYTES >= 4 ? 4 : (158 * 1024) / FIXED_BYTES;
+    static constexpr int NW0 = WGS >= 4 ? 2 : (WGS == 3 ? 3 : (WGS == 2 ? 4 : 8));
+    static constexpr int NW = NW0 > NT ? NT : NW0;
+    static constexpr int TQ = NT / NW, TR = NT % NW; // wavefronts below TR take TQ + 1 tiles
     static constexpr int NTHR = 64 * NW;
+    static_assert(WGS >= 1 && TQ >= 1, "geometry");
 };
+
+// index of pixel p inside a plane (with halo)
+template <int S> __device__ __forceinline__ int pix_index(int p)
+{
+    return (p / S + 1) * Geo<S>::ROW + p % S + 1;
+}
 
 // packed parameter block (floats), built by the host:
 //   first layer : B[5][64], scale[16], shift[16]
@@ -72,89 +77,229 @@ template <int KSTEPS> struct LayerRegs {
 };
 template <int KSTEPS> __device__ __forceinline__ void load_layer(const float *prm, int lane, LayerRegs<KSTEPS> &w)
 {
+    // One address register pair per 16 loads (the immediate offset of a load reaches 4 KB); the
+    // empty asm keeps the compiler from deriving, and keeping, a separate 64-bit address per load.
 #pragma unroll
-    for (int i = 0; i < KSTEPS; i++) w.b[i] = prm[i * 64 + lane];
-    w.sc = prm[KSTEPS * 64 + (lane & 15)];
-    w.sh = prm[KSTEPS * 64 + 16 + (lane & 15)];
+    for (int c = 0; c < (KSTEPS + 15) / 16; c++) {
+        const float *p = prm + c * 16 * 64 + lane;
+        asm volatile("" : "+v"(p));
+#pragma unroll
+        for (int i = c * 16; i < KSTEPS && i < c * 16 + 16; i++) w.b[i] = p[(i - c * 16) * 64];
+    }
+    const float *q = prm + KSTEPS * 64 + (lane & 15);
+    asm volatile("" : "+v"(q));
+    w.sc = q[0];
+    w.sh = q[16];
 }
 
-// one 3x3 convolution + folded batch norm + ReLU, `in` -> `out` (LDS planes).
-// KSTEPS = 36 for 16 input channels (tap-major, 4 channels per step), 5 for the
-// 2-plane input layer (K index = tap*2 + plane, padded with zero weights).
-template <int S, int KSTEPS>
-__device__ __forceinline__ void conv3x3(const float *in, float *out, const LayerRegs<KSTEPS> &w, int wave, int lane)
+// sum over the four lanes that hold the same output channel (lane ^ 16, lane ^ 32, lane ^ 48)
+__device__ __forceinline__ float sum_over_kq(float v)
+{
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+enum { MODE_WRITE = 0, MODE_VALUE_SUM = 1 };
+
+// What a lane needs to know about the tiles of its wavefront, computed once per
+// launch (kept few on purpose: everything here stays in registers for the whole kernel).
+//   rd[t]   : plane index of the pixel whose A operand this lane reads for tile t
+//             (+ this lane's channel-quarter plane, so a K step adds only a constant)
+//   wr[t]   : co*PS + plane index of the first of the lane's four output pixels of tile t
+//   wrap[t] : how many of those four pixels lie before a row end (4 = no row end inside)
+template <int NTMAX> struct TileMap {
+    int rd[NTMAX], wr[NTMAX], wrap[NTMAX];
+    int tile0;      // first tile of this wavefront (wave-uniform)
+    int last_valid; // pixels of the lane's four that exist in the board's last, partial tile
+    int crd, cwr;   // the same for the corner pixel of a board of 16k+1 pixels
+};
+template <int S> __device__ __forceinline__ void make_tile_map(int wave, int lane, TileMap<Geo<S>::TQ + 1> &m)
 {
     using G = Geo<S>;
     const int co = lane & 15, kq = lane >> 4;
-    constexpr int TPW = G::TPW;
-    for (int tile0 = wave * TPW; tile0 < G::NT; tile0 += 16) {
-        f32x4 acc[TPW];
-        int base[TPW];
+    m.tile0 = wave < G::TR ? wave * (G::TQ + 1) : G::TR * (G::TQ + 1) + (wave - G::TR) * G::TQ;
 #pragma unroll
-        for (int t = 0; t < TPW; t++) {
-            acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if constexpr (G::FLAT) {
-                int p = (tile0 + t) * 16 + (lane & 15);
-                p = p < G::SIZE ? p : G::SIZE - 1; // lanes past the board compute a pixel nobody stores
-                base[t] = (p / S + 1) * G::ROW + p % S + 1;
-            } else {
-                const int tile = tile0 + t < G::NT ? tile0 + t : G::NT - 1;
-                const int y = tile / G::TPR, x = (tile % G::TPR) * 16 + (lane & 15);
-                base[t] = (y + 1) * G::ROW + x + 1;
-            }
+    for (int t = 0; t < G::TQ + 1; t++) {
+        int p = (m.tile0 + t) * 16 + (lane & 15);
+        p = p < G::SIZE ? p : G::SIZE - 1; // lanes past the board read a pixel nobody stores
+        m.rd[t] = pix_index<S>(p) + kq * G::PS - (G::ROW + 1); // biased by the most negative tap offset: every K step adds a constant >= 0
+        int p0 = (m.tile0 + t) * 16 + kq * 4;
+        p0 = p0 < G::SIZE ? p0 : G::SIZE - 1;
+        m.wr[t] = co * G::PS + pix_index<S>(p0);
+        const int left = S - p0 % S;
+        m.wrap[t] = left < 4 ? left : 4;
+    }
+    const int rest = G::SIZE - ((G::NT - 1) * 16 + kq * 4);
+    m.last_valid = rest < 0 ? 0 : (rest > 4 ? 4 : rest);
+    m.crd = pix_index<S>(G::SIZE - 1) + kq * G::PS - (G::ROW + 1);
+    m.cwr = co * G::PS + pix_index<S>(G::SIZE - 1);
+}
+
+// One 3x3 convolution + folded batch norm + ReLU over the NTW tiles of this wavefront,
+// `src` -> `dst` (LDS planes; dst may be src: the results are written after a barrier
+// that follows the last read).
+// KSTEPS = 36 for 16 input channels (tap-major, 4 channels per step), 5 for the
+// 2-plane input layer (K index = tap*2 + plane, padded with zero weights; off0 =
+// this lane's operand offset for each of its five K indices, relative to plane 0).
+// CORNERW: this wavefront also computes the board's last pixel (boards of 16k+1 pixels).
+// MODE_VALUE_SUM: nothing is written; returns this lane's sum of its outputs (the
+// value head only needs the board sums per channel).
+template <int S, int KSTEPS, int NTW, bool CORNERW, int MODE>
+__device__ __forceinline__ float conv3x3(const float *src, float *dst, const LayerRegs<KSTEPS> &w, const int (&off0)[5],
+                                         const TileMap<Geo<S>::TQ + 1> &m, int lane)
+{
+    using G = Geo<S>;
+    const int kq = lane >> 4;
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float cacc = 0.f;
+    const int kqp = KSTEPS == 36 ? 0 : kq * G::PS; // the input layer's K index does not follow the channel quarters
+    // operand offset of K step ks (a constant after unrolling for the 16-channel layers)
+    auto koff = [&](int ks) {
+        if constexpr (KSTEPS == 36) {
+            const int tap = ks >> 2;
+            return (ks & 3) * 4 * G::PS + (tap / 3) * G::ROW + (tap % 3); // (relative to the biased rd[])
+        } else {
+            return off0[ks] - kqp + (G::ROW + 1);
+        }
+    };
+    // Software pipeline, one K step deep: the A operands of step ks+1 are requested
+    // before the matrix instructions of step ks are issued, and a scheduling barrier
+    // after every step keeps the compiler from hoisting the whole layer's reads to the
+    // top (which costs more registers than the file has).
+    // (the read bases pass through an empty asm per layer: otherwise every address of every
+    // layer is precomputed outside the position loop and the kernel runs out of registers)
+    int rd[NTW], crd = m.crd;
+#pragma unroll
+    for (int t = 0; t < NTW; t++) {
+        rd[t] = m.rd[t];
+        asm volatile("" : "+v"(rd[t]));
+    }
+    asm volatile("" : "+v"(crd));
+    float a[NTW], an[NTW], ca = 0.f, can = 0.f;
+#pragma unroll
+    for (int t = 0; t < NTW; t++) a[t] = src[rd[t] + koff(0)];
+    if constexpr (CORNERW) ca = src[crd + koff(0)];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++) {
+        if (ks + 1 < KSTEPS) {
+#pragma unroll
+            for (int t = 0; t < NTW; t++) an[t] = src[rd[t] + koff(ks + 1)];
+            if constexpr (CORNERW) can = src[crd + koff(ks + 1)];
         }
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ks++) {
-            int tap, ci;
-            if (KSTEPS == 36) { tap = ks >> 2; ci = (ks & 3) * 4 + kq; }
-            else { const int kk = ks * 4 + kq; tap = kk < 18 ? kk >> 1 : 0; ci = kk & 1; }
-            const int off = ci * G::PS + (tap / 3 - 1) * G::ROW + (tap % 3 - 1);
+        for (int t = 0; t < NTW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], w.b[ks], acc[t], 0, 0, 0);
+        if constexpr (CORNERW) cacc = fmaf(ca, w.b[ks], cacc);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < TPW; t++)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(in[base[t] + off], w.b[ks], acc[t], 0, 0, 0);
-        }
+        for (int t = 0; t < NTW; t++) a[t] = an[t];
+        ca = can;
+    }
+    if (MODE == MODE_WRITE && src == dst) __syncthreads(); // every wavefront has read its operands
+    float vsum = 0.f;
 #pragma unroll
-        for (int t = 0; t < TPW; t++) {
-            const int tile = tile0 + t;
-            if constexpr (G::FLAT) {
-                // accumulator register r of this lane: pixel tile*16 + kq*4 + r, channel co
-                const int p0 = tile * 16 + kq * 4;
-                int y = p0 / S, x = p0 % S;
+    for (int t = 0; t < NTW; t++) {
+        // accumulator register r of this lane: pixel tile*16 + kq*4 + r, channel co
+        const bool partial = G::SIZE % 16 != 0 && !G::CORNER && m.tile0 + t == G::NT - 1; // wave-uniform
+        int wr = m.wr[t], wrap = m.wrap[t];
+        asm volatile("" : "+v"(wr), "+v"(wrap));
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    if (p0 + r < G::SIZE)
-                        out[co * G::PS + (y + 1) * G::ROW + x + 1] = fmaxf(acc[t][r] * w.sc + w.sh, 0.f);
-                    if (++x == S) { x = 0; y++; }
-                }
-            } else if (tile < G::NT) {
-                const int y = tile / G::TPR, x0 = (tile % G::TPR) * 16 + kq * 4;
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    if (x0 + r < S)
-                        out[co * G::PS + (y + 1) * G::ROW + x0 + r + 1] = fmaxf(acc[t][r] * w.sc + w.sh, 0.f);
+        for (int r = 0; r < 4; r++) {
+            const float v = fmaxf(acc[t][r] * w.sc + w.sh, 0.f);
+            if (!partial || r < m.last_valid) {
+                if constexpr (MODE == MODE_WRITE) dst[wr + r + (r >= wrap ? 2 : 0)] = v; // a row end skips two halo cells
+                else vsum += v;
             }
         }
     }
+    if constexpr (CORNERW) {
+        const float v = fmaxf(sum_over_kq(cacc) * w.sc + w.sh, 0.f);
+        if (kq == 0) {
+            if constexpr (MODE == MODE_WRITE) dst[m.cwr] = v;
+            else vsum += v;
+        }
+    }
+    return vsum;
 }
 
-// policy head: 3x3 conv to one channel + bias, log-softmax over the board
+// the wavefront's share of a layer: wavefronts below TR take TQ + 1 tiles, the last
+// wavefront takes the corner pixel
+template <int S, int KSTEPS, int MODE>
+__device__ __forceinline__ float conv_layer(const float *src, float *dst, const LayerRegs<KSTEPS> &w, const int (&off0)[5],
+                                            const TileMap<Geo<S>::TQ + 1> &m, int wave, int lane)
+{
+    using G = Geo<S>;
+    if constexpr (G::TR != 0) {
+        if (wave < G::TR) return conv3x3<S, KSTEPS, G::TQ + 1, false, MODE>(src, dst, w, off0, m, lane);
+    }
+    if constexpr (G::CORNER) {
+        if (wave == G::NW - 1) return conv3x3<S, KSTEPS, G::TQ, true, MODE>(src, dst, w, off0, m, lane);
+    }
+    return conv3x3<S, KSTEPS, G::TQ, false, MODE>(src, dst, w, off0, m, lane);
+}
+
+// Policy head, first half: the 3x3 convolution to one channel is split into a 1x1
+// product on the matrix cores, T[tap][q] = sum_ci w[tap][ci] * src[ci][q] (N = the 9 taps),
+// written as 9 planes of `tb`; the logit of pixel p is then bias + sum_tap T[tap][p + offset(tap)].
+template <int S, int NTW, bool CORNERW>
+__device__ __forceinline__ void policy_taps(const float *src, float *tb, const float (&bp)[4],
+                                            const TileMap<Geo<S>::TQ + 1> &m, int lane)
+{
+    using G = Geo<S>;
+    const int n = lane & 15, kq = lane >> 4;
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float cacc = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+#pragma unroll
+        for (int t = 0; t < NTW; t++)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(src[m.rd[t] + ks * 4 * G::PS + (G::ROW + 1)], bp[ks], acc[t], 0, 0, 0);
+        if constexpr (CORNERW) cacc = fmaf(src[m.crd + ks * 4 * G::PS + (G::ROW + 1)], bp[ks], cacc);
+    }
+#pragma unroll
+    for (int t = 0; t < NTW; t++) {
+        const bool partial = G::SIZE % 16 != 0 && !G::CORNER && m.tile0 + t == G::NT - 1;
+        int wr = m.wr[t], wrap = m.wrap[t];
+        asm volatile("" : "+v"(wr), "+v"(wrap));
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (n < 9 && (!partial || r < m.last_valid)) tb[wr + r + (r >= wrap ? 2 : 0)] = acc[t][r];
+    }
+    if constexpr (CORNERW) {
+        const float v = sum_over_kq(cacc);
+        if (kq == 0 && n < 9) tb[m.cwr] = v;
+    }
+}
 template <int S>
-__device__ __forceinline__ void policy_head(const float *src, const float *p_policy, float *red, float *logit,
-                                            float *logp_row, int tid, int wave, int lane)
+__device__ __forceinline__ void policy_taps_layer(const float *src, float *tb, const float (&bp)[4],
+                                                  const TileMap<Geo<S>::TQ + 1> &m, int wave, int lane)
+{
+    using G = Geo<S>;
+    if constexpr (G::TR != 0) {
+        if (wave < G::TR) return policy_taps<S, G::TQ + 1, false>(src, tb, bp, m, lane);
+    }
+    if constexpr (G::CORNER) {
+        if (wave == G::NW - 1) return policy_taps<S, G::TQ, true>(src, tb, bp, m, lane);
+    }
+    policy_taps<S, G::TQ, false>(src, tb, bp, m, lane);
+}
+
+// Policy head, second half: gather of the 9 partial planes + bias, log-softmax over the board
+template <int S>
+__device__ __forceinline__ void policy_softmax(const float *tb, float bias, float *red, float *logit, float *logp_row,
+                                               int tid, int wave, int lane)
 {
     using G = Geo<S>;
     float lmax = -INFINITY;
     for (int p = tid; p < G::SIZE; p += G::NTHR) {
-        const int ctr = (p / S + 1) * G::ROW + p % S + 1;
-        float acc = p_policy[9 * CH];
-        // (taps not unrolled: with all 144 operand reads of a pixel hoisted at once the
-        // kernel runs out of registers and spills; 4 % slower at 15x15, 18 % at 20x20)
-#pragma unroll 1
-        for (int tap = 0; tap < 9; tap++) {
-            const int off = ctr + (tap / 3 - 1) * G::ROW + (tap % 3 - 1);
+        const int ctr = pix_index<S>(p);
+        float acc = bias;
 #pragma unroll
-            for (int ci = 0; ci < CH; ci++) acc += p_policy[tap * CH + ci] * src[ci * G::PS + off];
-        }
+        for (int tap = 0; tap < 9; tap++) acc += tb[tap * G::PS + ctr + (tap / 3 - 1) * G::ROW + (tap % 3 - 1)];
         logit[p] = acc;
         lmax = fmaxf(lmax, acc);
     }
@@ -169,40 +314,56 @@ __device__ __forceinline__ void policy_head(const float *src, const float *p_pol
     for (int p = tid; p < G::SIZE; p += G::NTHR) lsum += expf(logit[p] - lmax);
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) lsum += __shfl_xor(lsum, o);
-    if (lane == 0) red[G::NW + wave] = lsum;
+    if (lane == 0) red[8 + wave] = lsum;
     __syncthreads();
     float tot = 0.f;
 #pragma unroll
-    for (int w = 0; w < G::NW; w += 4) tot += (red[G::NW + w] + red[G::NW + w + 1]) + (red[G::NW + w + 2] + red[G::NW + w + 3]);
+    for (int w = 0; w < G::NW; w++) tot += red[8 + w];
     const float lse = lmax + logf(tot);
     for (int p = tid; p < G::SIZE; p += G::NTHR) logp_row[p] = logit[p] - lse;
-    __syncthreads(); // scratch and the branch buffers are free again
 }
 
 template <int S>
-__global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_eval(const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol,
-                                                  int val, float *value_out, float *logp_out)
+__global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_eval(const float *boards, const int *leaf_kind, int n, const float *prm,
+                                                           int front, int pol, int val, float *value_out, float *logp_out)
 {
     using G = Geo<S>;
     extern __shared__ float lds[];
-    float *A = lds, *B = lds + CH * G::PS, *C = lds + 2 * CH * G::PS;
-    float *red = lds + 3 * CH * G::PS; // [2 * NW] reduction scratch + logits [SIZE]
-    float *logit = red + 2 * G::NW;
+    float *F = lds, *W = lds + G::BUF;
+    float *red = lds + 2 * G::BUF;     // [16]: two reduction rows of up to 8 wavefronts
+    float *logit = red + 16;           // [SIZE]
     int *todo = reinterpret_cast<int *>(logit + G::SIZE); // [ceil(n / gridDim.x)] positions of this workgroup
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int i = tid; i < 3 * CH * G::PS; i += G::NTHR) lds[i] = 0.f; // halos stay zero from here on
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform: the per-wavefront variants branch on it
+    const int co = lane & 15, kq = lane >> 4;
+    for (int i = tid; i < 2 * G::BUF; i += G::NTHR) lds[i] = 0.f; // halos stay zero from here on
     __syncthreads();
-    const int nl = front - 1 + pol + val; // 16->16 layers: trunk, policy branch, value branch
+    const int nl = front - 1 + pol + val; // 16->16 layers: trunk, policy branch, value branch (parameter order)
     const float *p_layers = prm + FIRST_FLOATS;
     const float *p_policy = p_layers + (size_t)nl * LAYER_FLOATS;
     const float *p_value = p_policy + POLICY_FLOATS;
-    // Buffers: the input layer writes B, the trunk ping-pongs B <-> A and leaves
-    // `front` in F; X is the other one of {A, B}.  Each branch runs F -> X -> C -> X ...
-    float *F = ((front - 1) & 1) ? A : B;
-    float *X = ((front - 1) & 1) ? B : A;
-    const int head_at = front - 1 + pol; // 16->16 layers done when the policy head runs
+    // Execution order: trunk, VALUE branch, policy branch (the policy head then finds the
+    // trunk buffer free for its partial planes); parameters of execution step e:
+    auto layer_params = [&](int e) {
+        const int idx = e < front - 1 ? e : (e < front - 1 + val ? e + pol : e - val);
+        return p_layers + (size_t)idx * LAYER_FLOATS;
+    };
     LayerRegs<5> w0;
     load_layer<5>(prm, lane, w0);
+    int off0[5]; // input layer: K index kk = ks*4 + kq -> tap kk>>1 of plane kk&1
+#pragma unroll
+    for (int ks = 0; ks < 5; ks++) {
+        const int kk = ks * 4 + kq;
+        const int tap = kk < 18 ? kk >> 1 : 0;
+        off0[ks] = (kk & 1) * G::PS + (tap / 3 - 1) * G::ROW + (tap % 3 - 1);
+    }
+    TileMap<G::TQ + 1> tm;
+    make_tile_map<S>(wave, lane, tm);
+    float bp[4]; // policy head as a B operand: B[k = ci][n = tap]
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) bp[ks] = co < 9 ? p_policy[co * CH + ks * 4 + kq] : 0.f;
+    const float p_bias = p_policy[9 * CH];
+    const float wv = p_value[co], v_bias = p_value[CH];
 
     // Positions to evaluate: every gridDim.x-th one, counted among those that need an
     // evaluation (a search that ended on a finished game, or an idle tree, needs
@@ -211,11 +372,11 @@ __global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2,
     // second kernel.
     int n_mine;
     if (leaf_kind != nullptr) {
-        int *cnt = reinterpret_cast<int *>(red); // [NW] per-wavefront totals (scratch is free before the first head)
+        int *cnt = reinterpret_cast<int *>(red); // [NW] per-wavefront totals
         const int per = (n + G::NTHR - 1) / G::NTHR, lo = tid * per, hi = lo + per < n ? lo + per : n;
         int c = 0;
         for (int i = lo; i < hi; i++) c += leaf_kind[i] == AZ_LEAF_EXPAND;
-        int incl = c; // inclusive prefix over the wavefront, then over the four wavefronts
+        int incl = c; // inclusive prefix over the wavefront, then over the wavefronts
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int up = __shfl_up(incl, o);
@@ -241,75 +402,79 @@ __global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2,
     }
     for (int it = 0; it < n_mine; it++) {
         const int pos = leaf_kind != nullptr ? todo[it] : (int)blockIdx.x + it * (int)gridDim.x;
-        // raw planes into channels 0..1 of A (channels 2..15 of A may hold stale
-        // interior values of the previous position: the 2-plane layer never reads them)
+        // raw planes into channels 0..1 of W (its other channels may hold interior values of
+        // the previous position: the 2-plane layer never reads them)
         for (int i = tid; i < CIN * G::SIZE; i += G::NTHR) {
             const int c = i / G::SIZE, p = i - c * G::SIZE;
-            A[c * G::PS + (p / S + 1) * G::ROW + p % S + 1] = boards[(size_t)pos * CIN * G::SIZE + i];
+            W[c * G::PS + pix_index<S>(p)] = boards[(size_t)pos * CIN * G::SIZE + i];
         }
         // The parameters of the next convolution are requested one layer ahead, so
         // their L2 latency runs under the current layer's matrix instructions.
         LayerRegs<36> wq, wn;
-        if (nl > 0) load_layer<36>(p_layers, lane, wq);
+        if (nl > 0) load_layer<36>(layer_params(0), lane, wq);
         __syncthreads();
-        conv3x3<S, 5>(A, B, w0, wave, lane);
+        conv_layer<S, 5, MODE_WRITE>(W, F, w0, off0, tm, wave, lane);
         __syncthreads();
-        const float *head_src = F; // what the policy / value heads read when their branch is empty
-        if (head_at == 0) policy_head<S>(F, p_policy, red, logit, logp_out + (size_t)pos * G::SIZE, tid, wave, lane);
-        for (int l = 0; l < nl; l++) {
-            if (l + 1 < nl) load_layer<36>(p_layers + (size_t)(l + 1) * LAYER_FLOATS, lane, wn);
-            const float *src;
-            float *dst;
-            if (l < front - 1) { // trunk
-                src = (l & 1) ? A : B;
-                dst = (l & 1) ? B : A;
-            } else {             // branch layer j
-                const int j = l - (front - 1) - (l >= front - 1 + pol ? pol : 0);
-                src = j == 0 ? F : ((j & 1) ? X : C);
-                dst = (j & 1) ? C : X;
+        float vpart = 0.f; // this lane's share of the value head's sum
+        bool v_done = false;
+        for (int e = 0; e < nl; e++) {
+            if (e + 1 < nl) load_layer<36>(layer_params(e + 1), lane, wn);
+            // trunk: F in place.  A branch: F -> W, then W in place.
+            const bool trunk = e < front - 1;
+            const int j = trunk ? 0 : (e < front - 1 + val ? e - (front - 1) : e - (front - 1) - val);
+            const float *src = (trunk || j == 0) ? F : W;
+            float *dst = trunk ? F : W;
+            if (val > 0 && e == front - 1 + val - 1) {
+                // last layer of the value branch: only the per-channel board sums are needed
+                vpart = wv * conv_layer<S, 36, MODE_VALUE_SUM>(src, dst, wq, off0, tm, wave, lane);
+                v_done = true;
+            } else {
+                conv_layer<S, 36, MODE_WRITE>(src, dst, wq, off0, tm, wave, lane);
             }
-            conv3x3<S, 36>(src, dst, wq, wave, lane);
             __syncthreads();
-            head_src = dst;
-            if (l + 1 == head_at) {
-                policy_head<S>(head_src, p_policy, red, logit, logp_out + (size_t)pos * G::SIZE, tid, wave, lane);
-                head_src = F; // the value branch starts from the trunk output again
+            if (e + 1 < nl) wq = wn;
+        }
+        if (!v_done) { // no value branch: the head reads the trunk output
+            for (int p = tid; p < G::SIZE; p += G::NTHR) {
+                const int ctr = pix_index<S>(p);
+#pragma unroll
+                for (int ci = 0; ci < CH; ci++) vpart += p_value[ci] * F[ci * G::PS + ctr];
             }
-            if (l + 1 < nl) wq = wn;
-        }
-        // ---- value head: 1x1 conv + bias, board average, tanh
-        float vs = 0.f;
-        for (int p = tid; p < G::SIZE; p += G::NTHR) {
-            const int ctr = (p / S + 1) * G::ROW + p % S + 1;
-#pragma unroll
-            for (int ci = 0; ci < CH; ci++) vs += p_value[ci] * head_src[ci * G::PS + ctr];
+            __syncthreads(); // the policy head's partial planes may go into F
         }
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) vs += __shfl_xor(vs, o);
-        if (lane == 0) red[wave] = vs;
+        for (int o = 1; o < 64; o <<= 1) vpart += __shfl_xor(vpart, o);
+        // ---- policy head: partial planes on the matrix cores, gather + log-softmax
+        const float *hsrc = pol > 0 ? W : F;
+        float *tb = pol > 0 ? F : W;
+        policy_taps_layer<S>(hsrc, tb, bp, tm, wave, lane);
+        if (lane == 0) red[wave] = vpart;
         __syncthreads();
-        if (tid == 0) {
+        if (tid == 0) { // ---- value head: board average of the 1x1 convolution + bias, tanh
             float vt = 0.f;
 #pragma unroll
-            for (int w = 0; w < G::NW; w += 4) vt += (red[w] + red[w + 1]) + (red[w + 2] + red[w + 3]);
-            value_out[pos] = tanhf(vt / (float)G::SIZE + p_value[CH]);
+            for (int w = 0; w < G::NW; w++) vt += red[w];
+            value_out[pos] = tanhf(vt / (float)G::SIZE + v_bias);
         }
-        __syncthreads();
+        __syncthreads(); // red is reused by the softmax
+        policy_softmax<S>(tb, p_bias, red, logit, logp_out + (size_t)pos * G::SIZE, tid, wave, lane);
+        // No barrier here: every read of tb's planes precedes the two barriers inside the
+        // softmax, and the next position first writes W's input planes, which nobody reads
+        // at this point (tb == W only when there is no policy branch, and then the gather
+        // is over for every wavefront that has left the softmax).
     }
 }
 
-template <int S> int launch(const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val, float *value_out,
-                            float *logp_out, hipStream_t st)
+template <int S> int launch(const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val,
+                            float *value_out, float *logp_out, hipStream_t st)
 {
     using G = Geo<S>;
-    const size_t fixed_bytes = (size_t)(3 * CH * G::PS + 2 * G::NW + G::SIZE) * sizeof(float);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int per_cu = (int)(160 * 1024 / fixed_bytes) > 0 ? (int)(160 * 1024 / fixed_bytes) : 1;
-    int grid = cus * per_cu;
+    int grid = cus * G::WGS;
     if (grid > n) grid = n;
     // + the workgroup's own list of positions (at most ceil(n / grid) entries)
-    const size_t lds_bytes = fixed_bytes + (size_t)((n + grid - 1) / grid) * sizeof(int);
+    const size_t lds_bytes = (size_t)G::FIXED_BYTES + (size_t)((n + grid - 1) / grid) * sizeof(int);
     // largest size the kernel has been opened up to, per device (the attribute is per device)
     static size_t configured[64] = {};
     if (dev < 0 || dev >= 64 || lds_bytes > configured[dev]) {
@@ -318,8 +483,8 @@ template <int S> int launch(const float *boards, const int *leaf_kind, int n, co
             return AZ_ERR_HIP;
         if (dev >= 0 && dev < 64) configured[dev] = lds_bytes;
     }
-    hipLaunchKernelGGL(k_net_eval<S>, dim3(grid), dim3(G::NTHR), lds_bytes, st, boards, leaf_kind, n, prm, front, pol, val, value_out,
-                       logp_out);
+    hipLaunchKernelGGL(k_net_eval<S>, dim3(grid), dim3(G::NTHR), lds_bytes, st, boards, leaf_kind, n, prm, front, pol, val,
+                       value_out, logp_out);
     return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
 }
 

@@ -22,6 +22,7 @@
 // gather; the value head is summed from the registers of the last value layer.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/azmcts.h"
 
@@ -465,6 +466,419 @@ __global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2,
     }
 }
 
+
+// ---------------------------------------------------------------------------------
+// Boards up to 15x15: ONE wavefront per position (a workgroup of 64 threads), eight
+// positions per CU.  Nothing is shared between wavefronts, so there is no barrier
+// anywhere: the two wavefronts of a SIMD drift freely against each other and one
+// computes while the other is in an epilogue or a head.  A single activation buffer
+// per position (every layer runs in place: all 14 tiles of a 15x15 board are held as
+// accumulators, then overwrite the input); the trunk output, which both branches
+// start from, waits in registers while the value branch uses the buffer.
+// The weights of the next layer replace the current ones register by register as the
+// K steps retire them, so one set of weight registers serves the whole network.
+template <int S> struct SoloGeo {
+    using G = Geo<S>;
+    static constexpr int NT = G::NT;
+    static constexpr int LDS_BYTES = G::BUF * 4;
+    static constexpr int WGS0 = (160 * 1024 - 2048) / (LDS_BYTES + 256);
+    static constexpr int WGS = WGS0 > 8 ? 8 : WGS0;
+};
+
+template <int S> struct SoloMap { // per-lane addressing of the tiles, fixed for the whole launch
+    int rd[Geo<S>::NT];   // A-operand pixel of tile t (+ channel-quarter plane, biased by -(ROW+1))
+    // byte offset of the lane's first output cell of tile t (co*PS + pixel; bits 0..14), and for cells
+    // 1..3 whether a row end (two halo cells, 8 bytes) lies before them: 8 or 0 in byte 2 (cell 1) and
+    // byte 3 (cell 2), bit 15 for cell 3
+    int wrpk[Geo<S>::NT];
+    int crd, cwr;         // the corner pixel of a board of 16k+1 pixels
+    int last_valid;       // pixels of the lane's four that exist in a partial last tile
+};
+template <int S> __device__ __forceinline__ void make_solo_map(int lane, SoloMap<S> &m)
+{
+    using G = Geo<S>;
+    const int co = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < G::NT; t++) {
+        int p = t * 16 + (lane & 15);
+        p = p < G::SIZE ? p : G::SIZE - 1;
+        m.rd[t] = pix_index<S>(p) + kq * G::PS - (G::ROW + 1);
+        int p0 = t * 16 + kq * 4;
+        p0 = p0 < G::SIZE ? p0 : G::SIZE - 1;
+        const int left = S - p0 % S;
+        m.wrpk[t] = ((co * G::PS + pix_index<S>(p0)) * 4) | (left <= 3 ? 1 << 15 : 0) | (left <= 1 ? 8 << 16 : 0) |
+                    (left <= 2 ? 8 << 24 : 0);
+        static_assert(G::BUF * 4 < (1 << 15), "cell offsets need 15 bits");
+    }
+    const int rest = G::SIZE - ((G::NT - 1) * 16 + kq * 4);
+    m.last_valid = rest < 0 ? 0 : (rest > 4 ? 4 : rest);
+    m.crd = pix_index<S>(G::SIZE - 1) + kq * G::PS - (G::ROW + 1);
+    m.cwr = co * G::PS + pix_index<S>(G::SIZE - 1);
+}
+
+
+// Stores the lane's four cells of one tile (see SoloMap::wrpk): one address instruction per cell.
+template <int S, bool PARTIAL>
+__device__ __forceinline__ void store_cells(float *buf, int pk, int last_valid, const float (&v)[4])
+{
+    asm volatile("" : "+v"(pk)); // (not hoisted: precomputed addresses of all tiles would not fit the register file)
+    const unsigned u = (unsigned)pk;
+    char *a0 = reinterpret_cast<char *>(buf) + (u & 0x7fffu);
+    char *a1 = a0 + ((u >> 16) & 0xffu), *a2 = a0 + (u >> 24), *a3 = a0 + ((u >> 12) & 8u);
+    if (!PARTIAL || 0 < last_valid) *reinterpret_cast<float *>(a0) = v[0];
+    if (!PARTIAL || 1 < last_valid) *reinterpret_cast<float *>(a1 + 4) = v[1];
+    if (!PARTIAL || 2 < last_valid) *reinterpret_cast<float *>(a2 + 8) = v[2];
+    if (!PARTIAL || 3 < last_valid) *reinterpret_cast<float *>(a3 + 12) = v[3];
+}
+
+// The matrix part of one convolution over all tiles: acc[t] += A(tile t) x B for every K
+// step.  The A operands of step ks+1 are requested into the registers step ks has just
+// consumed, one request after each matrix instruction (scheduling groups), so a request
+// is 13 matrix instructions ahead of its use.  ROLL: w.b[ks] is reloaded from `nextp`
+// (the next layer's block) as soon as step ks is done with it.
+template <int S, int KSTEPS, bool ROLL>
+__device__ __forceinline__ void solo_mma(const float *buf, LayerRegs<KSTEPS> &w, const float *nextp, const SoloMap<S> &m,
+                                         const int (&off0)[5], int lane, float init, f32x4 (&acc)[Geo<S>::NT], float &cacc)
+{
+    using G = Geo<S>;
+    constexpr int NT = G::NT;
+    const int kq = lane >> 4;
+    const int kqp = KSTEPS == 36 ? 0 : kq * G::PS;
+    auto koff = [&](int ks) {
+        if constexpr (KSTEPS == 36) {
+            const int tap = ks >> 2;
+            return (ks & 3) * 4 * G::PS + (tap / 3) * G::ROW + (tap % 3);
+        } else if constexpr (KSTEPS == 4) { // 1x1 product of the policy head: the centre tap
+            return ks * 4 * G::PS + (G::ROW + 1);
+        } else {
+            return off0[ks] - kqp + (G::ROW + 1);
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = (f32x4){init, init, init, init};
+    cacc = 0.f;
+    // Issue priority: low inside the matrix loop, high everywhere else.  The other wavefront
+    // of the SIMD is usually in its own matrix loop; its long matrix instructions lose
+    // nothing when this wavefront's short vector phases (epilogues, heads) go first, and
+    // those phases take half the time.
+    __builtin_amdgcn_s_setprio(0);
+    // (the input layer's offsets vary per lane: its 5 x NT addresses are formed when needed,
+    // from a base the compiler cannot trace, instead of living in registers all along)
+    int rd[NT], crd = m.crd;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        rd[t] = m.rd[t];
+        if constexpr (KSTEPS == 5) asm volatile("" : "+v"(rd[t]));
+    }
+    if constexpr (KSTEPS == 5) asm volatile("" : "+v"(crd));
+    float a[NT], ca = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; t++) a[t] = buf[rd[t] + koff(0)];
+    if constexpr (G::CORNER) ca = buf[crd + koff(0)];
+    const float *np = nextp + lane;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++) {
+        __builtin_amdgcn_sched_barrier(0);
+        const float b = w.b[ks];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b, acc[t], 0, 0, 0);
+            if (ks + 1 < KSTEPS) a[t] = buf[rd[t] + koff(ks + 1)];
+        }
+        if constexpr (G::CORNER) {
+            cacc = fmaf(ca, b, cacc);
+            if (ks + 1 < KSTEPS) ca = buf[crd + koff(ks + 1)];
+        }
+        if constexpr (ROLL) w.b[ks] = np[ks * 64];
+        if (ks + 1 < KSTEPS) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // one matrix instruction
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // one LDS read
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(3);
+}
+
+// ReLU of the accumulators (they started from the folded batch-norm shift, the scale is in
+// the weights).  WRITE: back into the buffer; KEEP: also into the private copy of the trunk
+// output; SUM: nothing is stored, the lane's outputs are added up for the value head.
+enum { EP_WRITE = 1, EP_KEEP = 2, EP_SUM = 4 };
+template <int S, int FLAGS>
+__device__ __forceinline__ void solo_epilogue(float *buf, const f32x4 (&acc)[Geo<S>::NT], float cacc, float sh,
+                                              const SoloMap<S> &m, int lane, float *fc, int fz, float &vsum)
+{
+    using G = Geo<S>;
+    const int kq = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < G::NT; t++) {
+        constexpr bool dummy = false;
+        (void)dummy;
+        const bool partial = G::SIZE % 16 != 0 && !G::CORNER && t == G::NT - 1; // compile-time per t after unrolling
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = __builtin_amdgcn_fmed3f(acc[t][r], 0.f, INFINITY); // ReLU in one instruction
+        if constexpr ((FLAGS & EP_WRITE) != 0) {
+            if (partial) store_cells<S, true>(buf, m.wrpk[t], m.last_valid, v);
+            else store_cells<S, false>(buf, m.wrpk[t], 4, v);
+        }
+        if constexpr ((FLAGS & EP_KEEP) != 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) fc[fz + t * 4 + r] = v[r];
+        }
+        if constexpr ((FLAGS & EP_SUM) != 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) vsum += (!partial || r < m.last_valid) ? v[r] : 0.f;
+        }
+    }
+    if constexpr (G::CORNER) {
+        const float v = __builtin_amdgcn_fmed3f(sum_over_kq(cacc) + sh, 0.f, INFINITY);
+        if constexpr ((FLAGS & EP_KEEP) != 0) fc[fz + G::NT * 4] = v;
+        if (kq == 0) {
+            if constexpr ((FLAGS & EP_WRITE) != 0) buf[m.cwr] = v;
+            if constexpr ((FLAGS & EP_SUM) != 0) vsum += v;
+        }
+    }
+}
+// the trunk output back from its private copy
+template <int S> __device__ __forceinline__ void solo_restore(float *buf, const SoloMap<S> &m, int lane, const float *fc, int fz)
+{
+    using G = Geo<S>;
+#pragma unroll
+    for (int t = 0; t < G::NT; t++) {
+        const bool partial = G::SIZE % 16 != 0 && !G::CORNER && t == G::NT - 1;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = fc[fz + t * 4 + r];
+        if (partial) store_cells<S, true>(buf, m.wrpk[t], m.last_valid, v);
+        else store_cells<S, false>(buf, m.wrpk[t], 4, v);
+    }
+    if (G::CORNER && (lane >> 4) == 0) buf[m.cwr] = fc[fz + G::NT * 4];
+}
+
+template <int S>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_solo(
+    const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val, float *value_out,
+    float *logp_out)
+{
+    using G = Geo<S>;
+    constexpr int NT = G::NT;
+    extern __shared__ float lds[];
+    float *buf = lds;
+    int *todo = reinterpret_cast<int *>(lds + G::BUF); // [ceil(n / gridDim.x)] positions of this workgroup
+    const int lane = threadIdx.x;
+    const int co = lane & 15, kq = lane >> 4;
+    for (int i = lane; i < G::BUF; i += 64) buf[i] = 0.f; // halos stay zero from here on
+    const int nl = front - 1 + pol + val;
+    const float *p_layers = prm + FIRST_FLOATS;
+    const float *p_policy = p_layers + (size_t)nl * LAYER_FLOATS;
+    const float *p_value = p_policy + POLICY_FLOATS;
+    // execution order: trunk, value branch, policy branch (parameter order: trunk, policy, value)
+    auto layer_params = [&](int e) {
+        const int idx = e < front - 1 ? e : (e < front - 1 + val ? e + pol : e - val);
+        return p_layers + (size_t)idx * LAYER_FLOATS;
+    };
+    LayerRegs<5> w0;
+    load_layer<5>(prm, lane, w0);
+    int off0[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ks++) {
+        const int kk = ks * 4 + kq;
+        const int tap = kk < 18 ? kk >> 1 : 0;
+        off0[ks] = (kk & 1) * G::PS + (tap / 3 - 1) * G::ROW + (tap % 3 - 1);
+    }
+    SoloMap<S> m;
+    make_solo_map<S>(lane, m);
+    LayerRegs<4> wp; // policy head as a B operand: B[k = ci][n = tap]
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) wp.b[ks] = co < 9 ? p_policy[co * CH + ks * 4 + kq] : 0.f;
+    wp.sc = wp.sh = 0.f;
+    const float p_bias = p_policy[9 * CH];
+    const float wv = p_value[co], v_bias = p_value[CH];
+
+    int n_mine;
+    if (leaf_kind != nullptr) {
+        const int per = (n + 63) / 64, lo = lane * per, hi = lo + per < n ? lo + per : n;
+        int c = 0;
+        for (int i = lo; i < hi; i++) c += leaf_kind[i] == AZ_LEAF_EXPAND;
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        const int total = __shfl(incl, 63);
+        int before = incl - c;
+        for (int i = lo; i < hi; i++)
+            if (leaf_kind[i] == AZ_LEAF_EXPAND) {
+                if (before % (int)gridDim.x == (int)blockIdx.x) todo[before / (int)gridDim.x] = i;
+                before++;
+            }
+        n_mine = total > (int)blockIdx.x ? (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    } else {
+        n_mine = n > (int)blockIdx.x ? (n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    }
+    __syncthreads(); // (a single wavefront: orders the LDS traffic, costs nothing)
+
+#ifdef AZ_NET_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_0 = __builtin_readcyclecounter();
+#define NST(i) do { unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_t; st_t = t_; } while (0)
+#else
+#define NST(i) do { } while (0)
+#endif
+    f32x4 acc[NT];
+    float cacc = 0.f;
+    // The trunk output, which both branches start from, is parked in private memory while the
+    // value branch owns the buffer (one store and one load per value and position; the
+    // register file has no room for a second set of NT tiles).  Indexed through a value the
+    // compiler cannot see through, so that the array really lives in memory.
+    float fc[NT * 4 + 1];
+    int fz;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(fz));
+    // pixels this lane loads, gathers and stores: lane, lane + 64, ...
+    constexpr int PPL = (G::SIZE + 63) / 64;
+    for (int it = 0; it < n_mine; it++) {
+        const int pos = leaf_kind != nullptr ? todo[it] : (int)blockIdx.x + it * (int)gridDim.x;
+#ifdef AZ_NET_STAMPS
+        st_t = __builtin_readcyclecounter();
+#endif
+        {   // the two input planes into planes 0..1 of the buffer
+            const float *bp = boards + (size_t)pos * CIN * G::SIZE;
+            int l0 = lane;
+            asm volatile("" : "+v"(l0));
+#pragma unroll
+            for (int i = 0; i < PPL; i++) {
+                const int p = l0 + 64 * i;
+                if (p < G::SIZE) {
+                    const int ctr = pix_index<S>(p);
+                    buf[ctr] = bp[p];
+                    buf[G::PS + ctr] = bp[G::SIZE + p];
+                }
+            }
+        }
+        LayerRegs<36> wq;
+        if (nl > 0) load_layer<36>(layer_params(0), lane, wq);
+        __syncthreads();
+        float vsum = 0.f;
+        NST(0);
+        // input layer; it is also the trunk's last layer when front == 1
+        solo_mma<S, 5, false>(buf, w0, prm, m, off0, lane, w0.sh, acc, cacc);
+        NST(6);
+        if (front > 1) solo_epilogue<S, EP_WRITE>(buf, acc, cacc, w0.sh, m, lane, fc, fz, vsum);
+        else if (val > 0) solo_epilogue<S, EP_WRITE | EP_KEEP>(buf, acc, cacc, w0.sh, m, lane, fc, fz, vsum);
+        else solo_epilogue<S, EP_WRITE | EP_SUM>(buf, acc, cacc, w0.sh, m, lane, fc, fz, vsum);
+        __syncthreads();
+        NST(2);
+        for (int e = 0; e < nl; e++) {
+            const bool last_trunk = e == front - 2;
+            const bool last_value = val > 0 && e == front - 1 + val - 1;
+            const bool first_policy = pol > 0 && e == front - 1 + val;
+            if (first_policy && val > 0) { // the trunk output comes back from its private copy
+                solo_restore<S>(buf, m, lane, fc, fz);
+                __syncthreads();
+            }
+            const float *nextp = layer_params(e + 1 < nl ? e + 1 : e);
+            const float sh = wq.sh;
+            NST(4);
+            solo_mma<S, 36, true>(buf, wq, nextp, m, off0, lane, sh, acc, cacc);
+            NST(1);
+            wq.sh = nextp[36 * 64 + 16 + co];
+            if (last_value) solo_epilogue<S, EP_SUM>(buf, acc, cacc, sh, m, lane, fc, fz, vsum);
+            else if (last_trunk && val > 0) solo_epilogue<S, EP_WRITE | EP_KEEP>(buf, acc, cacc, sh, m, lane, fc, fz, vsum);
+            else if (last_trunk) solo_epilogue<S, EP_WRITE | EP_SUM>(buf, acc, cacc, sh, m, lane, fc, fz, vsum);
+            else solo_epilogue<S, EP_WRITE>(buf, acc, cacc, sh, m, lane, fc, fz, vsum);
+            __syncthreads();
+            NST(2);
+        }
+        // policy head input: the policy branch's output, or the trunk output when there is no such branch
+        if (pol == 0 && val > 0) {
+            solo_restore<S>(buf, m, lane, fc, fz);
+            __syncthreads();
+        }
+        // ---- value head: board average of the 1x1 convolution + bias, tanh
+        float vpart = wv * vsum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) vpart += __shfl_xor(vpart, o);
+        if (lane == 0) value_out[pos] = tanhf(vpart / (float)G::SIZE + v_bias);
+        // ---- policy head: per-tap partial planes on the matrix cores, written over the input
+        solo_mma<S, 4, false>(buf, wp, prm, m, off0, lane, 0.f, acc, cacc);
+        if (co < 9) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const bool partial = G::SIZE % 16 != 0 && !G::CORNER && t == NT - 1;
+                const float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+                if (partial) store_cells<S, true>(buf, m.wrpk[t], m.last_valid, v);
+                else store_cells<S, false>(buf, m.wrpk[t], 4, v);
+            }
+        }
+        if constexpr (G::CORNER) {
+            const float v = sum_over_kq(cacc);
+            if (kq == 0 && co < 9) buf[m.cwr] = v;
+        }
+        __syncthreads();
+        // gather of the nine planes + bias, log-softmax over the board
+        float logit[PPL];
+        float lmax = -INFINITY;
+        int l1 = lane;
+        asm volatile("" : "+v"(l1));
+#pragma unroll
+        for (int i = 0; i < PPL; i++) {
+            const int p = l1 + 64 * i;
+            const int ctr = pix_index<S>(p < G::SIZE ? p : 0);
+            float s = p_bias;
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) s += buf[tap * G::PS + ctr + (tap / 3 - 1) * G::ROW + (tap % 3 - 1)];
+            logit[i] = p < G::SIZE ? s : -INFINITY;
+            lmax = fmaxf(lmax, logit[i]);
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+        float lsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) lsum += lane + 64 * i < G::SIZE ? expf(logit[i] - lmax) : 0.f;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) lsum += __shfl_xor(lsum, o);
+        const float lse = lmax + logf(lsum);
+#pragma unroll
+        for (int i = 0; i < PPL; i++)
+            if (lane + 64 * i < G::SIZE) logp_out[(size_t)pos * G::SIZE + lane + 64 * i] = logit[i] - lse;
+        __syncthreads(); // the gather is over before the next position's input lands in the buffer
+        NST(3);
+        // planes 2..15 keep leftovers (partial planes, old activations): the input layer reads planes 0..1 only
+    }
+#ifdef AZ_NET_STAMPS
+    if (lane == 0 && n_mine > 0 && leaf_kind == nullptr) { // diagnostic build: cycle sums over the log-priors of the first position
+        st_acc[5] = __builtin_readcyclecounter() - st_0;
+        st_acc[7] = (unsigned long long)n_mine;
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(logp_out + (size_t)blockIdx.x * G::SIZE);
+        for (int q = 0; q < 8; q++) o[q] = st_acc[q];
+    }
+#endif
+}
+
+template <int S> int launch_solo(const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val,
+                                 float *value_out, float *logp_out, hipStream_t st)
+{
+    using G = Geo<S>;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int grid = cus * SoloGeo<S>::WGS;
+    if (grid > n) grid = n;
+    const size_t lds_bytes = (size_t)SoloGeo<S>::LDS_BYTES + (size_t)((n + grid - 1) / grid) * sizeof(int);
+    static size_t configured[64] = {};
+    if (dev < 0 || dev >= 64 || lds_bytes > configured[dev]) {
+        if (hipFuncSetAttribute((const void *)k_net_solo<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) !=
+            hipSuccess)
+            return AZ_ERR_HIP;
+        if (dev >= 0 && dev < 64) configured[dev] = lds_bytes;
+    }
+    hipLaunchKernelGGL(k_net_solo<S>, dim3(grid), dim3(64), lds_bytes, st, boards, leaf_kind, n, prm, front, pol, val, value_out,
+                       logp_out);
+    return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
+}
+
 template <int S> int launch(const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val,
                             float *value_out, float *logp_out, hipStream_t st)
 {
@@ -505,9 +919,14 @@ int az_net_eval(int shape, int n, const float *d_boards, const int *d_leaf_kind,
     if (n == 0) return AZ_OK;
     if (!d_boards || !d_params || !d_value || !d_logp) return AZ_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    static const bool team = getenv("AZ_NET_TEAM") != nullptr; // tuning override: the multi-wavefront kernel for every shape
     switch (shape) {
-#define AZ_NET_CASE(s) \
-    case s: return launch<s>(d_boards, d_leaf_kind, n, d_params, front_layers, policy_layers, value_layers, d_value, d_logp, st);
+#define AZ_NET_CASE(s)                                                                                                   \
+    case s:                                                                                                              \
+        if (s <= 15 && !team)                                                                                            \
+            return launch_solo<(s <= 15 ? s : 15)>(d_boards, d_leaf_kind, n, d_params, front_layers, policy_layers,      \
+                                                   value_layers, d_value, d_logp, st);                                   \
+        return launch<s>(d_boards, d_leaf_kind, n, d_params, front_layers, policy_layers, value_layers, d_value, d_logp, st);
         AZ_NET_CASE(5) AZ_NET_CASE(6) AZ_NET_CASE(7) AZ_NET_CASE(8) AZ_NET_CASE(9) AZ_NET_CASE(10) AZ_NET_CASE(11)
         AZ_NET_CASE(12) AZ_NET_CASE(13) AZ_NET_CASE(14) AZ_NET_CASE(15) AZ_NET_CASE(16) AZ_NET_CASE(17)
         AZ_NET_CASE(18) AZ_NET_CASE(19) AZ_NET_CASE(20)

@@ -120,8 +120,10 @@ class FusedNetEvaluator:
             kk = ks * 4 + kq
             ok = kk < 18
             tap, ci = torch.where(ok, kk >> 1, 0), kk & 1
-            b[ks] = torch.where(ok, w[co, ci, tap // 3, tap % 3], torch.zeros(64, dtype=torch.float64))
-        out += [b.reshape(-1), sc, sh]
+            b[ks] = torch.where(ok, w[co, ci, tap // 3, tap % 3] * sc[co], torch.zeros(64, dtype=torch.float64))
+        # (the inference batch-norm scale is folded into the weights; the kernels add the shift only,
+        # the scale slot of the block stays for layout compatibility and holds ones)
+        out += [b.reshape(-1), torch.ones_like(sc), sh]
         blocks = [("front", i) for i in range(1, front)] + [("policy_conv", i) for i in range(pol)] + \
                  [("value_conv", i) for i in range(val)]
         for prefix, i in blocks:
@@ -131,8 +133,8 @@ class FusedNetEvaluator:
             b = torch.zeros(36, 64, dtype=torch.float64)
             for tap in range(9):
                 for g in range(4):
-                    b[tap * 4 + g] = w[co, 4 * g + kq, tap // 3, tap % 3]
-            out += [b.reshape(-1), sc, sh]
+                    b[tap * 4 + g] = w[co, 4 * g + kq, tap // 3, tap % 3] * sc[co]
+            out += [b.reshape(-1), torch.ones_like(sc), sh]
         wp = state["policy.0.weight"].detach().double().cpu()  # [1,16,3,3]
         out += [wp[0].permute(1, 2, 0).reshape(-1), state["policy.0.bias"].detach().double().cpu().reshape(-1)]
         wv = state["value.0.weight"].detach().double().cpu()   # [1,16,1,1]

@@ -739,13 +739,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     asm volatile("s_mov_b32 %0, 0" : "=s"(fz));
     // pixels this lane loads, gathers and stores: lane, lane + 64, ...
     constexpr int PPL = (G::SIZE + 63) / 64;
+    float in0[PPL], in1[PPL]; // the next position's input planes, requested one position ahead
+    auto request_board = [&](int pos) {
+        const float *bp = boards + (size_t)pos * CIN * G::SIZE;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) {
+            const int p = lane + 64 * i;
+            in0[i] = p < G::SIZE ? bp[p] : 0.f;
+            in1[i] = p < G::SIZE ? bp[G::SIZE + p] : 0.f;
+        }
+    };
+    if (n_mine > 0) request_board(leaf_kind != nullptr ? todo[0] : (int)blockIdx.x);
+    // the weights of the first 16-channel layer: loaded here once, later rolled in by the last layer
+    LayerRegs<36> wq;
+    if (nl > 0) load_layer<36>(layer_params(0), lane, wq);
     for (int it = 0; it < n_mine; it++) {
         const int pos = leaf_kind != nullptr ? todo[it] : (int)blockIdx.x + it * (int)gridDim.x;
 #ifdef AZ_NET_STAMPS
         st_t = __builtin_readcyclecounter();
 #endif
-        {   // the two input planes into planes 0..1 of the buffer
-            const float *bp = boards + (size_t)pos * CIN * G::SIZE;
+        {   // the two input planes (requested while the previous position was in its heads) into planes 0..1
             int l0 = lane;
             asm volatile("" : "+v"(l0));
 #pragma unroll
@@ -753,13 +766,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const int p = l0 + 64 * i;
                 if (p < G::SIZE) {
                     const int ctr = pix_index<S>(p);
-                    buf[ctr] = bp[p];
-                    buf[G::PS + ctr] = bp[G::SIZE + p];
+                    buf[ctr] = in0[i];
+                    buf[G::PS + ctr] = in1[i];
                 }
             }
         }
-        LayerRegs<36> wq;
-        if (nl > 0) load_layer<36>(layer_params(0), lane, wq);
         __syncthreads();
         float vsum = 0.f;
         NST(0);
@@ -779,7 +790,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 solo_restore<S>(buf, m, lane, fc, fz);
                 __syncthreads();
             }
-            const float *nextp = layer_params(e + 1 < nl ? e + 1 : e);
+            const float *nextp = layer_params(e + 1 < nl ? e + 1 : 0); // (the last layer fetches the next position's first)
             const float sh = wq.sh;
             NST(4);
             solo_mma<S, 36, true>(buf, wq, nextp, m, off0, lane, sh, acc, cacc);
@@ -802,6 +813,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) vpart += __shfl_xor(vpart, o);
         if (lane == 0) value_out[pos] = tanhf(vpart / (float)G::SIZE + v_bias);
+        if (it + 1 < n_mine) request_board(leaf_kind != nullptr ? todo[it + 1] : (int)blockIdx.x + (it + 1) * (int)gridDim.x);
         // ---- policy head: per-tap partial planes on the matrix cores, written over the input
         solo_mma<S, 4, false>(buf, wp, prm, m, off0, lane, 0.f, acc, cacc);
         if (co < 9) {

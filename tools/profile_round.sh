@@ -28,5 +28,8 @@ timeout -s KILL 170 rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" -o p --output
 echo fetch done
 timeout -s KILL 170 rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_write" -o p --output-format csv -- $B > "$out/pmc_write.log" 2>&1
 echo write done
-python3 tools/summarize_prof.py "$tag" "$out/stats" "$out/pmc_sq" "$out/pmc_sq2" "$out/pmc_fetch" "$out/pmc_write"
+# matrix-core and LDS counters (the network kernel's bound)
+timeout -s KILL 170 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_IDX_ACTIVE -d "$out/pmc_mfma" -o p --output-format csv -- $B > "$out/pmc_mfma.log" 2>&1
+echo mfma done
+python3 tools/summarize_prof.py "$tag" "$out/stats" "$out/pmc_sq" "$out/pmc_sq2" "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_mfma"
 cp profiles/${tag}_kernel_stats.csv profiles/${tag}_pmc.json profiles/traffic.json "$out/" 2>/dev/null || true

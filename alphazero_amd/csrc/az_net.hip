@@ -152,9 +152,11 @@ __device__ __forceinline__ float conv3x3(const float *src, float *dst, const Lay
 {
     using G = Geo<S>;
     const int kq = lane >> 4;
+    // (the batch-norm scale is folded into the weights by the host: the accumulators start
+    // from the shift and the epilogue is the ReLU alone)
     f32x4 acc[NTW];
 #pragma unroll
-    for (int t = 0; t < NTW; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NTW; t++) acc[t] = (f32x4){w.sh, w.sh, w.sh, w.sh};
     float cacc = 0.f;
     const int kqp = KSTEPS == 36 ? 0 : kq * G::PS; // the input layer's K index does not follow the channel quarters
     // operand offset of K step ks (a constant after unrolling for the 16-channel layers)
@@ -166,10 +168,6 @@ __device__ __forceinline__ float conv3x3(const float *src, float *dst, const Lay
             return off0[ks] - kqp + (G::ROW + 1);
         }
     };
-    // Software pipeline, one K step deep: the A operands of step ks+1 are requested
-    // before the matrix instructions of step ks are issued, and a scheduling barrier
-    // after every step keeps the compiler from hoisting the whole layer's reads to the
-    // top (which costs more registers than the file has).
     // (the read bases pass through an empty asm per layer: otherwise every address of every
     // layer is precomputed outside the position loop and the kernel runs out of registers)
     int rd[NTW], crd = m.crd;
@@ -179,25 +177,39 @@ __device__ __forceinline__ float conv3x3(const float *src, float *dst, const Lay
         asm volatile("" : "+v"(rd[t]));
     }
     asm volatile("" : "+v"(crd));
-    float a[NTW], an[NTW], ca = 0.f, can = 0.f;
+    // The A operands of step ks+1 are requested into the registers step ks has just consumed,
+    // one request after each matrix instruction (scheduling groups): a request is NTW - 1
+    // matrix instructions ahead of its use.  Issue priority is low inside this loop and high
+    // outside it: the vector phases of a wavefront go first while the other wavefront of the
+    // SIMD issues long matrix instructions.
+    float a[NTW], ca = 0.f;
 #pragma unroll
     for (int t = 0; t < NTW; t++) a[t] = src[rd[t] + koff(0)];
     if constexpr (CORNERW) ca = src[crd + koff(0)];
+    __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ks++) {
+        __builtin_amdgcn_sched_barrier(0);
+        const float b = w.b[ks];
+#pragma unroll
+        for (int t = 0; t < NTW; t++) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b, acc[t], 0, 0, 0);
+            if (ks + 1 < KSTEPS) a[t] = src[rd[t] + koff(ks + 1)];
+        }
+        if constexpr (CORNERW) {
+            cacc = fmaf(ca, b, cacc);
+            if (ks + 1 < KSTEPS) ca = src[crd + koff(ks + 1)];
+        }
         if (ks + 1 < KSTEPS) {
 #pragma unroll
-            for (int t = 0; t < NTW; t++) an[t] = src[rd[t] + koff(ks + 1)];
-            if constexpr (CORNERW) can = src[crd + koff(ks + 1)];
+            for (int t = 0; t < NTW; t++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // one matrix instruction
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // one LDS read
+            }
         }
-#pragma unroll
-        for (int t = 0; t < NTW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], w.b[ks], acc[t], 0, 0, 0);
-        if constexpr (CORNERW) cacc = fmaf(ca, w.b[ks], cacc);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < NTW; t++) a[t] = an[t];
-        ca = can;
     }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(3);
     if (MODE == MODE_WRITE && src == dst) __syncthreads(); // every wavefront has read its operands
     float vsum = 0.f;
 #pragma unroll
@@ -206,17 +218,18 @@ __device__ __forceinline__ float conv3x3(const float *src, float *dst, const Lay
         const bool partial = G::SIZE % 16 != 0 && !G::CORNER && m.tile0 + t == G::NT - 1; // wave-uniform
         int wr = m.wr[t], wrap = m.wrap[t];
         asm volatile("" : "+v"(wr), "+v"(wrap));
+        float *d0 = dst + wr, *d1 = d0 + 2; // a row end skips two halo cells
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const float v = fmaxf(acc[t][r] * w.sc + w.sh, 0.f);
+            const float v = __builtin_amdgcn_fmed3f(acc[t][r], 0.f, INFINITY); // ReLU
             if (!partial || r < m.last_valid) {
-                if constexpr (MODE == MODE_WRITE) dst[wr + r + (r >= wrap ? 2 : 0)] = v; // a row end skips two halo cells
+                if constexpr (MODE == MODE_WRITE) (r >= wrap ? d1 : d0)[r] = v;
                 else vsum += v;
             }
         }
     }
     if constexpr (CORNERW) {
-        const float v = fmaxf(sum_over_kq(cacc) * w.sc + w.sh, 0.f);
+        const float v = __builtin_amdgcn_fmed3f(sum_over_kq(cacc) + w.sh, 0.f, INFINITY);
         if (kq == 0) {
             if constexpr (MODE == MODE_WRITE) dst[m.cwr] = v;
             else vsum += v;

@@ -265,7 +265,7 @@ def secondary_hash(torch, E, dev_index, name, trees, shape, nodes, traffic):
     }
 
 
-def secondary_net(torch, E, dev_index, trees=8192, shape=SHAPE, sims=SIMS):
+def secondary_net(torch, E, dev_index, trees=8192, shape=SHAPE, sims=SIMS, label="config3"):
     """Config 3: `trees` concurrent games, random-init reference network (seed 0) evaluated
     by the library's fused f32 matrix-core kernel, one batched evaluation per search
     step, Dirichlet noise drawn on the GPU (eps 0.25, default alpha), cpuct 4."""
@@ -317,7 +317,7 @@ def secondary_net(torch, E, dev_index, trees=8192, shape=SHAPE, sims=SIMS):
             st = eng.get_stats()
             achieved_tf = trees * net_flops_per_position(shape) / (t_net / 1e3) / 1e12
             return {
-                "workload": f"config3: {shape}x{shape}, {trees} concurrent trees, random-init reference net "
+                "workload": f"{label}: {shape}x{shape}, {trees} concurrent trees, random-init reference net "
                             "(fused f32 matrix-core kernel), one batched leaf evaluation per search step, "
                             f"eps=0.25, cpuct=4, one move = {sims} search steps queued by az_simulate_net",
                 "value": st["sims"] / elapsed, "unit": "sims/s", "timed_s": elapsed, "search_steps": sims,
@@ -334,7 +334,13 @@ def secondary_net(torch, E, dev_index, trees=8192, shape=SHAPE, sims=SIMS):
         finally:
             tb.close()
     except Exception as e:
-        return {"workload": "config3", "error": f"{type(e).__name__}: {e}"}
+        return {"workload": label, "error": f"{type(e).__name__}: {e}"}
+
+
+def config4_share(torch, E, dev_index):
+    """One GPU's share of config 4 (65,536 games of 20x20 over 8 GPUs = 8192 per GPU):
+    the network-evaluated search at that width; 200 search steps timed."""
+    return secondary_net(torch, E, dev_index, trees=8192, shape=20, sims=200, label="config4 (one GPU's 8192 of 65536 games)")
 
 
 # secondary tree-only workloads: name -> (trees, board edge, node-pool slots per tree)
@@ -386,7 +392,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--only", default=None,
                     help="run one secondary workload alone and print its record (for profiling): "
-                         + ", ".join(list(HASH_WORKLOADS) + ["config3"]))
+                         + ", ".join(list(HASH_WORKLOADS) + ["config3", "config4_share"]))
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -428,6 +434,7 @@ def main():
 
     if args.only:
         rec = (secondary_net(torch, E, dev_index) if args.only == "config3"
+               else config4_share(torch, E, dev_index) if args.only == "config4_share"
                else secondary_hash(torch, E, dev_index, args.only, *HASH_WORKLOADS[args.only], traffic))
         print(json.dumps(rec), flush=True)
         return
@@ -489,6 +496,7 @@ def main():
                 "tree_only_hash": [secondary_hash(torch, E, dev_index, name, *cfg, traffic)
                                    for name, cfg in HASH_WORKLOADS.items()],
                 "config3": secondary_net(torch, E, dev_index),
+                "config4_share": config4_share(torch, E, dev_index),
             }
         print(json.dumps(out), flush=True)
     if dist is not None:

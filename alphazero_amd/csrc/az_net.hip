@@ -44,10 +44,11 @@ template <int S> struct Geo {
     static constexpr int NT = CORNER ? SIZE / 16 : (SIZE + 15) / 16; // 16-pixel tiles
     static constexpr int BUF = CH * PS;             // floats of one activation buffer
     static constexpr int FIXED_BYTES = (2 * BUF + SIZE + 16) * 4;
-    // workgroups per CU by LDS, and wavefronts per workgroup so that a CU holds about
-    // eight wavefronts (two per SIMD)
-    static constexpr int WGS = (158 * 1024) / FIXED_BYTES >= 4 ? 4 : (158 * 1024) / FIXED_BYTES;
-    static constexpr int NW0 = WGS >= 4 ? 2 : (WGS == 3 ? 3 : (WGS == 2 ? 4 : 8));
+    // Workgroups per CU and wavefronts per workgroup: the kernel is built for two wavefronts
+    // per SIMD (256 registers each), i.e. eight per CU: four workgroups of two where the LDS
+    // holds four positions, else two workgroups of four.
+    static constexpr int WGS = (158 * 1024) / FIXED_BYTES >= 4 ? 4 : 2;
+    static constexpr int NW0 = WGS == 4 ? 2 : 4;
     static constexpr int NW = NW0 > NT ? NT : NW0;
     static constexpr int TQ = NT / NW, TR = NT % NW; // wavefronts below TR take TQ + 1 tiles
     static constexpr int NTHR = 64 * NW;

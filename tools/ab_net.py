@@ -20,7 +20,7 @@ if len(sys.argv) > 2 and sys.argv[1] == 'child':
         ts.append(e0.elapsed_time(e1))
     print(statistics.median(ts))
 else:
-    for S in (15, 20):
+    for S in (tuple(int(x) for x in os.environ["AB_SHAPES"].split(",")) if "AB_SHAPES" in os.environ else (15, 20)):
         for lib in sys.argv[1:]:
             out = subprocess.run([sys.executable, __file__, 'child', lib, str(S)], capture_output=True, text=True)
             print(S, lib, out.stdout.strip().splitlines()[-1] if out.returncode == 0 else out.stderr[-300:])

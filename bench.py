@@ -337,6 +337,53 @@ def secondary_net(torch, E, dev_index, trees=8192, shape=SHAPE, sims=SIMS, label
         return {"workload": label, "error": f"{type(e).__name__}: {e}"}
 
 
+def secondary_games(torch, dev_index, mode, games=4096, shape=SHAPE, sims=100, tau=10):
+    """Whole games end to end on one GPU through the batched drivers: `self_play_game`
+    (src/self_play.py:134-202; records assembled on the host, as the sample gather takes
+    them) or the arena's `eval_game` with two networks and the noise on (src/eval.py:187-209,
+    config 5).  Wall time includes every host step of the drivers."""
+    try:
+        from alphazero_amd import selfplay as sp
+        from alphazero_amd.evaluator import FusedNetEvaluator
+        from alphazero_amd.model import PolicyValueNet
+
+        dev = torch.device("cuda", dev_index)
+        nets = []
+        for seed in (0, 1):
+            torch.manual_seed(seed)
+            nets.append(FusedNetEvaluator(PolicyValueNet(shape).eval(), shape, dev, name=f"seed{seed}"))
+        second = nets[0] if mode == "selfplay" else nets[1]
+        nodes = sims * 3 + 64
+        b0 = sp.TreeBatch(games, shape, nets[0], cpuct=CPUCT, eps=0.25, nodes_per_tree=nodes, device=dev_index, noise_seed=0)
+        b1 = sp.TreeBatch(games, shape, second, cpuct=CPUCT, eps=0.25, nodes_per_tree=nodes, device=dev_index, noise_seed=1000)
+        try:
+            first = np.arange(games, dtype=np.int32) % (shape * shape)  # distinct first stones
+            b0.make_move(first)
+            b1.make_move(first)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            rec = {"workload": f"{mode}: {games} games of {shape}x{shape} to the end, {sims} sims/move, reference net "
+                               f"(seed 0{'' if mode == 'selfplay' else ' vs seed 1'}), eps=0.25, cpuct=4"}
+            if mode == "selfplay":
+                data = sp.self_play_games_device(b0, b1, sims, tau, rng=np.random.default_rng(0))
+                n_samples = sum(len(g) for g in data)
+            else:
+                rec["wins_first_net"], rec["wins_second_net"], rec["draws"] = (
+                    int(x) for x in sp.eval_games_device(b0, b1, sims, sims))
+            torch.cuda.synchronize(dev)
+            wall = time.perf_counter() - t0
+            total = b0.eng.get_stats()["sims"] + b1.eng.get_stats()["sims"]
+            rec.update({"value": total / wall, "unit": "sims/s", "wall_s": wall, "games_per_s": games / wall})
+            if mode == "selfplay":
+                rec.update({"samples": n_samples, "samples_per_s": n_samples / wall})
+            return rec
+        finally:
+            b0.close()
+            b1.close()
+    except Exception as e:
+        return {"workload": mode, "error": f"{type(e).__name__}: {e}"}
+
+
 def config4_share(torch, E, dev_index):
     """One GPU's share of config 4 (65,536 games of 20x20 over 8 GPUs = 8192 per GPU):
     the network-evaluated search at that width; 200 search steps timed."""
@@ -392,7 +439,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--only", default=None,
                     help="run one secondary workload alone and print its record (for profiling): "
-                         + ", ".join(list(HASH_WORKLOADS) + ["config3", "config4_share"]))
+                         + ", ".join(list(HASH_WORKLOADS) + ["config3", "config4_share", "config3_games", "config5_share"]))
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -435,6 +482,8 @@ def main():
     if args.only:
         rec = (secondary_net(torch, E, dev_index) if args.only == "config3"
                else config4_share(torch, E, dev_index) if args.only == "config4_share"
+               else secondary_games(torch, dev_index, "selfplay") if args.only == "config3_games"
+               else secondary_games(torch, dev_index, "arena") if args.only == "config5_share"
                else secondary_hash(torch, E, dev_index, args.only, *HASH_WORKLOADS[args.only], traffic))
         print(json.dumps(rec), flush=True)
         return
@@ -497,6 +546,8 @@ def main():
                                    for name, cfg in HASH_WORKLOADS.items()],
                 "config3": secondary_net(torch, E, dev_index),
                 "config4_share": config4_share(torch, E, dev_index),
+                "config3_games": secondary_games(torch, dev_index, "selfplay"),
+                "config5_share": secondary_games(torch, dev_index, "arena"),
             }
         print(json.dumps(out), flush=True)
     if dist is not None:

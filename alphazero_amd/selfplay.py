@@ -210,6 +210,44 @@ def self_play_games(batch0, batch1, sims, tau, init_moves=(), rng=None):
     return out
 
 
+def _assemble_records(torch, dev, slabs, outcome, shape):
+    """Training records of many games from per-half-move device slabs, assembled ON THE GPU.
+    slabs: list of (step, side, pi [G,SIZE] device, board [G,2,S,S] device, played bool[G],
+    game_of int64[G]); outcome[game] = the game's winner (0 / 1, anything else = draw).
+    Returns (records, bounds): one structured array (sample_dtype) ordered by game, first
+    player's records first, ply order inside a side, and the per-game slice bounds.  The
+    ordering keys are small host arrays; the record bytes move once, device -> host."""
+    dt = sample_dtype(shape)
+    size = shape * shape
+    n_games = len(outcome)
+    if not slabs:
+        return np.zeros(0, dt), np.zeros(n_games + 1, np.int64)
+    G = slabs[0][2].shape[0]
+    played = np.stack([sl[4] for sl in slabs])                       # [H, G]
+    games = np.stack([sl[5] for sl in slabs])                        # [H, G]
+    h_idx, g_idx = np.nonzero(played)
+    game = games[h_idx, g_idx]
+    side = np.array([sl[1] for sl in slabs], np.int64)[h_idx]
+    step = np.array([sl[0] for sl in slabs], np.int64)[h_idx]
+    order = np.lexsort((step, side, game))
+    flat = torch.from_numpy((h_idx * G + g_idx)[order]).to(dev)
+    won = outcome[game[order]]
+    decided = (won == 0.0) | (won == 1.0)
+    r = np.where(decided, np.where(won == side[order], 1.0, -1.0), 1e-3).astype(np.float32)  # src/self_play.py:188-200
+    n = flat.numel()
+    out = torch.empty((n, 3 * size + 1), dtype=torch.float32, device=dev)
+    boards = torch.stack([sl[3] for sl in slabs]).reshape(len(slabs) * G, 2 * size)
+    out[:, :2 * size].copy_(boards.index_select(0, flat))
+    del boards
+    pis = torch.stack([sl[2] for sl in slabs]).reshape(len(slabs) * G, size)
+    out[:, 2 * size:3 * size].copy_(pis.index_select(0, flat))
+    del pis
+    out[:, 3 * size].copy_(torch.from_numpy(r))
+    rec = out.cpu().numpy().view(dt).reshape(n)
+    bounds = np.searchsorted(game[order], np.arange(n_games + 1))
+    return rec, bounds
+
+
 def self_play_games_device(batch0, batch1, sims, tau, init_moves=(), rng=None):
     """self_play_games with the per-move work kept on the GPU: visit-count
     distribution, move choice, the record's board and pi (az_choose_moves) and
@@ -259,41 +297,16 @@ def self_play_games_device(batch0, batch1, sims, tau, init_moves=(), rng=None):
         if not alive.any():
             break
     winner = batch0.winners()
-    dt = sample_dtype(S)
-    host = []
+    slab_list = []
     for side in (0, 1):
-        if slabs[side]:
-            pis = torch.stack([p for p, _ in slabs[side]]).cpu().numpy()      # [plies, G, SIZE]
-            boards = torch.stack([b for _, b in slabs[side]]).cpu().numpy()   # [plies, G, 2, S, S]
-            mask = np.stack(played[side])                                      # [plies, G]
-        else:
-            pis = np.zeros((0, G, size), np.float32)
-            boards = np.zeros((0, G, 2, S, S), np.float32)
-            mask = np.zeros((0, G), bool)
-        host.append((pis, boards, mask))
-    out = []
-    for g in range(G):
-        parts = []
-        for side in (0, 1):
-            pis, boards, mask = host[side]
-            sel = mask[:, g]
-            rec = np.zeros(int(sel.sum()), dt)
-            rec["board"] = boards[sel, g]
-            rec["pi"] = pis[sel, g]
-            rec["r"] = -1.0
-            parts.append(rec)
-        if winner[g] == 0.0:
-            parts[0]["r"] = 1.0
-        elif winner[g] == 1.0:
-            parts[1]["r"] = 1.0
-        else:
-            parts[0]["r"] = 1e-3
-            parts[1]["r"] = 1e-3
-        out.append(np.concatenate(parts))
-    return out
+        for step, ((pi, board), alive_then) in enumerate(zip(slabs[side], played[side])):
+            slab_list.append((step, side, pi, board, alive_then, np.arange(G, dtype=np.int64)))
+    rec, bounds = _assemble_records(torch, dev, slab_list, np.asarray(winner, np.float32), S)
+    return [rec[bounds[g]:bounds[g + 1]] for g in range(G)]
 
 
-def self_play_stream(batch0, batch1, sims, tau, n_games, init_moves=(), rng=None, flush_plies=32):
+def self_play_stream(batch0, batch1, sims, tau, n_games, init_moves=(), rng=None, flush_plies=None,
+                     device_record_bytes=48 << 30):
     """`n_games` games of `self_play_game` (src/self_play.py:134-202) on the G tree
     slots of the two batches, a finished game's slot being cleared and handed to
     the next game instead of idling until the longest game of the batch is over
@@ -306,6 +319,9 @@ def self_play_stream(batch0, batch1, sims, tau, n_games, init_moves=(), rng=None
     first player of every live game moves on even half-steps), so a game that
     ends on an even half-step leaves its slot empty for one half-step.  `rng`
     supplies one uniform number per sampling game and half-step, in slot order.
+    The per-half-step pi / board slabs stay on the GPU and are turned into records there at
+    the end (`_assemble_records`); `flush_plies` (or slabs beyond `device_record_bytes`)
+    selects the bounded-memory path that moves them to the host every so many half-steps.
     Returns the list of per-game record arrays in game order."""
     torch = batch0.torch
     rng = np.random.default_rng() if rng is None else rng
@@ -393,12 +409,16 @@ def self_play_stream(batch0, batch1, sims, tau, n_games, init_moves=(), rng=None
         alive &= ~done
         if side == 1:
             pair[alive] += 1
-        if len(slabs) >= flush_plies:
+        slab_bytes = len(slabs) * G * (3 * size + 1) * 4
+        if (flush_plies is not None and len(slabs) >= flush_plies) or (rec_parts and len(slabs) >= 32) or \
+                slab_bytes > device_record_bytes:
             flush()
         half += 1
+    if not rec_parts:  # everything is still on the GPU: order and label the records there
+        slab_list = [(step, step & 1, pi, board, played, games) for step, pi, board, played, games in slabs]
+        rec, bounds = _assemble_records(torch, dev, slab_list, outcome, S)
+        return [rec[bounds[g]:bounds[g + 1]] for g in range(n_games)]
     flush()
-    if not rec_parts:
-        return [np.zeros(0, dt) for _ in range(n_games)]
     rec = np.concatenate(rec_parts)
     key = np.concatenate(key_parts)
     order = np.lexsort((key[:, 2], key[:, 1], key[:, 0]))  # by game, first player's records first, ply order

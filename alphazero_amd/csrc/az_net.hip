@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <utility>
 
 #include "../../include/azmcts.h"
 
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2,
 template <int S> struct SoloGeo {
     using G = Geo<S>;
     static constexpr int NT = G::NT;
-    static constexpr int LDS_BYTES = G::BUF * 4;
+    static constexpr int LDS_BYTES = (G::BUF + 64) * 4; // + the zero tail and the dump cell of the Winograd layers
     static constexpr int WGS0 = (160 * 1024 - 2048) / (LDS_BYTES + 256);
     static constexpr int WGS = WGS0 > 8 ? 8 : WGS0;
 };
@@ -672,7 +673,304 @@ template <int S> __device__ __forceinline__ void solo_restore(float *buf, const 
     if (G::CORNER && (lane >> 4) == 0) buf[m.cwr] = fc[fz + G::NT * 4];
 }
 
-template <int S>
+
+// ---------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) form of the 16 -> 16 channel layers for the one-wavefront kernel:
+// a 2x2 block of outputs comes from the 4x4 input patch around it through 16 element-wise
+// products in a transformed domain instead of 36 multiply-adds per output pair, so a layer
+// needs 16 (transformed positions) x 4 (K steps) matrix instructions per 16 tiles: 256 per
+// 15x15 board against 504 for the direct form.
+//   M = 16 tiles of 2x2 outputs (tile T = block*16 + m, row-major over the board's tile grid)
+//   K = 4 input channels, N = the 16 output channels
+//   lane (m, kq) loads the 4x4 patch of ITS tile and channel 4*ks + kq, transforms it in
+//   registers (32 additions: V = Bt d B) and the 16 results ARE its A operands of the 16
+//   matrix instructions of this K step; the B operands are the host-transformed weights
+//   (U = G g Gt, batch-norm scale folded in), 64 registers for a whole layer.
+//   After the fourth K step a lane holds, for each of four tiles, the 16 transformed sums of
+//   its output channel; the inverse transform (24 additions per tile, done on 4-vectors over
+//   the lane's four tiles) gives the 2x2 outputs.  The batch-norm shift enters through the
+//   initial value of the four accumulators that each feed exactly one output.
+// The layer runs in place: the outputs of a block are written one block late, after every
+// patch of the following block has been requested (a block's patches reach one row and one
+// column into its neighbours).  Patches of the last tile row / column read one cell past the
+// halo: that is the next row's halo, the next plane's top halo or the zero tail behind the
+// last plane.
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression
+// in the body (the scheduling-group builtins only take literals)
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f)
+{
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int S> struct WinoGeo {
+    static constexpr int TW = (S + 1) / 2;       // tiles per board row
+    static constexpr int TILES = TW * TW;
+    static constexpr int NB = (TILES + 15) / 16; // blocks of 16 tiles
+    static constexpr unsigned DIV = 65536 / TW + 1; // T / TW == (T * DIV) >> 16 for T < 64
+};
+constexpr int WINO_TAIL = 32;             // zero floats behind the last plane (a patch may reach ROW + 1 floats past it)
+constexpr int WINO_DUMP = WINO_TAIL;      // + ROW + 2 cells that take the stores of tiles outside the board
+constexpr int WINO_FLOATS = 64 * 64 + CH; // U[16 positions][4 K steps][64 lanes], shift[16]
+
+template <int S> __device__ __forceinline__ void load_wino(const float *prm, int lane, float (&u)[64])
+{
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const float *p = prm + c * 16 * 64 + lane;
+        asm volatile("" : "+v"(p));
+#pragma unroll
+        for (int i = 0; i < 16; i++) u[c * 16 + i] = p[i * 64];
+    }
+}
+
+// The 2x2 outputs o[q][r] (q = 2*row + column inside the tile, r = the lane's r-th tile of block
+// mb) of this lane's output channel: cells outside the board (last row / column of an odd board)
+// are replaced by zero and stored all the same, they land on the halo.  `cob` = float offset of
+// the channel's plane + one halo row and column.  wr: store into the buffer; keep: also into the
+// private copy; sum: the lane's sum of the stored values is added to lsum.
+// Tile order inside a block of 16: row-major over the board's tile grid, except on boards with
+// eight tiles per row, where m = 2*tx + (ty & 1) (two tile rows per block, horizontally
+// adjacent tiles two lanes apart): every offset below is then a constant on top of one lane value.
+template <int S, bool wr, bool keep, bool sum>
+__device__ __forceinline__ void wino_store(float *buf, int mb, int cob, int kq, float (&o)[4][4], float *fc, int fz, float &lsum)
+{
+    using G = Geo<S>;
+    using W = WinoGeo<S>;
+    constexpr bool ODD = (S & 1) != 0;
+    if constexpr (W::TW == 8) {
+        float *base = buf + cob + 4 * kq; // tile column 2*kq
+        const bool edge = kq == 3;        // tiles r = 2, 3 are the last of their rows
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int ty = 2 * mb + (r & 1);
+            const bool below = !ODD || ty != W::TW - 1; // (a constant)
+            if (ODD && r >= 2) {
+                o[1][r] = edge ? 0.f : o[1][r];
+                o[3][r] = edge ? 0.f : o[3][r];
+            }
+            if (!below) o[2][r] = o[3][r] = 0.f;
+            float *c = base + ty * 2 * G::ROW + (r >> 1) * 2;
+            if constexpr (wr) {
+                c[0] = o[0][r];
+                c[1] = o[1][r];
+                if (below) { // (the row below the board is halo and stays zero)
+                    c[G::ROW] = o[2][r];
+                    c[G::ROW + 1] = o[3][r];
+                }
+            }
+            if constexpr (sum) lsum += (o[0][r] + o[1][r]) + (o[2][r] + o[3][r]);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const unsigned T = (unsigned)(mb * 16 + r) + 4u * (unsigned)kq;
+            const unsigned ty = (T * W::DIV) >> 16, tx = T - ty * W::TW;
+            int off = cob + (int)(ty * (2 * G::ROW) + tx * 2);
+            const bool valid = W::TILES % 16 == 0 || T < (unsigned)W::TILES;
+            if (ODD) {
+                const bool right = tx != W::TW - 1, below = ty != W::TW - 1;
+                o[1][r] = right ? o[1][r] : 0.f;
+                o[2][r] = below ? o[2][r] : 0.f;
+                o[3][r] = right && below ? o[3][r] : 0.f;
+            }
+            if (!valid) {
+                off = G::BUF + WINO_DUMP;
+#pragma unroll
+                for (int q = 0; q < 4; q++) o[q][r] = 0.f;
+            }
+            if constexpr (wr) {
+                float *c = buf + off;
+                c[0] = o[0][r];
+                c[1] = o[1][r];
+                c[G::ROW] = o[2][r];
+                c[G::ROW + 1] = o[3][r];
+            }
+            if constexpr (sum) lsum += (o[0][r] + o[1][r]) + (o[2][r] + o[3][r]);
+        }
+    }
+    if constexpr (keep) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) fc[fz + mb * 16 + q * 4 + r] = o[q][r];
+    }
+}
+
+// value of `v` two lanes up inside the row of 16 lanes, zero for the last two lanes
+__device__ __forceinline__ float from_lane_plus_2(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x102 /* row_shl:2 */, 0xf, 0xf, true));
+}
+
+template <int S, bool wr, bool keep, bool sum>
+__device__ __forceinline__ void wino_layer(float *buf, float (&u)[64], const float *nextp, float sh, int lane, float *fc,
+                                           int fz, float &lsum)
+{
+    using G = Geo<S>;
+    using W = WinoGeo<S>;
+    constexpr int NB = W::NB, NC = NB * 4;
+    constexpr bool FAST = W::TW == 8; // eight tiles per row: neighbouring tiles share half of their patches through DPP
+    constexpr int ND = FAST ? 8 : 16; // patch cells a lane loads per K step
+    int l = lane;
+    asm volatile("" : "+v"(l)); // (addresses are formed per layer instead of living in registers across the position loop)
+    const int kq = l >> 4, co = l & 15;
+    const int cob = co * G::PS + G::ROW + 1;
+    int pbase[NB];
+#pragma unroll
+    for (int mb = 0; mb < NB; mb++) {
+        if constexpr (FAST) {
+            pbase[mb] = kq * G::PS + (2 * (2 * mb + (co & 1))) * G::ROW + 2 * (co >> 1);
+        } else {
+            unsigned T = (unsigned)(mb * 16 + co);
+            if (W::TILES % 16 != 0) T = T < (unsigned)W::TILES ? T : (unsigned)W::TILES - 1;
+            const unsigned ty = (T * W::DIV) >> 16, tx = T - ty * W::TW;
+            pbase[mb] = (int)(kq * G::PS + 2 * ty * G::ROW + 2 * tx);
+        }
+    }
+    auto load_patch = [&](int c, float (&d)[ND]) {
+        int po = pbase[c >> 2] + (c & 3) * 4 * G::PS;
+        asm("" : "+v"(po)); // one address per patch; the cells are immediate offsets (not volatile: a volatile
+                            // statement orders every memory access around it and the patches could not be requested early)
+        const float *p = buf + po;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < ND / 4; j++) d[i * (ND / 4) + j] = p[i * G::ROW + j];
+    };
+    auto transform = [&](const float (&d)[ND], float (&a)[16]) {
+        if constexpr (FAST) {
+            // columns 0..1 of the patch are this lane's; columns 2..3 are columns 0..1 of the tile to the
+            // right, whose column sums sit two lanes up (zero behind the last tile of a row: halo)
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                t[j] = d[j] - d[4 + j];
+                t[2 + j] = d[2 + j] + d[4 + j];
+                t[4 + j] = d[4 + j] - d[2 + j];
+                t[6 + j] = d[2 + j] - d[6 + j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float t2 = from_lane_plus_2(t[i * 2]), t3 = from_lane_plus_2(t[i * 2 + 1]);
+                a[i * 4] = t[i * 2] - t2;
+                a[i * 4 + 1] = t[i * 2 + 1] + t2;
+                a[i * 4 + 2] = t2 - t[i * 2 + 1];
+                a[i * 4 + 3] = t[i * 2 + 1] - t3;
+            }
+        } else {
+            float t[16];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                t[j] = d[j] - d[8 + j];
+                t[4 + j] = d[4 + j] + d[8 + j];
+                t[8 + j] = d[8 + j] - d[4 + j];
+                t[12 + j] = d[4 + j] - d[12 + j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                a[i * 4] = t[i * 4] - t[i * 4 + 2];
+                a[i * 4 + 1] = t[i * 4 + 1] + t[i * 4 + 2];
+                a[i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1];
+                a[i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
+            }
+        }
+    };
+    float a[16], d[ND];
+    load_patch(0, d);
+    transform(d, a);
+    if (NC > 1) load_patch(1, d);
+    f32x4 acc[16];
+    float pend[4][4];
+    const float *np = nextp + l;
+    __builtin_amdgcn_s_setprio(0);
+    static_for<NC>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        constexpr int mb = c >> 2, ks = c & 3;
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks == 0) {
+#pragma unroll
+            for (int x = 0; x < 16; x++) {
+                const float v = (x == 0 || x == 15) ? sh : ((x == 3 || x == 12) ? -sh : 0.f);
+                acc[x] = (f32x4){v, v, v, v};
+            }
+        }
+        float an[16];
+        if (c + 1 < NC) transform(d, an);
+        if (c + 2 < NC) load_patch(c + 2, d);
+        // (column by column: the inverse transform's column sums can start while the last products run)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int x = i * 4 + j;
+                acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], u[x * 4 + ks], acc[x], 0, 0, 0);
+            }
+        if (mb == NB - 1) { // the next layer's weights replace this layer's as their last use retires
+            const float *p = np + ks * 64;
+            asm("" : "+v"(p));
+#pragma unroll
+            for (int x = 0; x < 16; x++) u[x * 4 + ks] = p[x * 4 * 64];
+        }
+        if (ks == 2 && mb > 0) wino_store<S, wr, keep, sum>(buf, mb - 1, cob, kq, pend, fc, fz, lsum);
+        if (ks == 3) {
+            // (element by element: packed additions cost more issue time next to matrix instructions than two plain ones)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float s[8];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    s[j] = acc[j][r] + acc[4 + j][r] + acc[8 + j][r];
+                    s[4 + j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+                }
+                pend[0][r] = __builtin_amdgcn_fmed3f(s[0] + s[1] + s[2], 0.f, INFINITY);
+                pend[1][r] = __builtin_amdgcn_fmed3f(s[1] - s[2] - s[3], 0.f, INFINITY);
+                pend[2][r] = __builtin_amdgcn_fmed3f(s[4] + s[5] + s[6], 0.f, INFINITY);
+                pend[3][r] = __builtin_amdgcn_fmed3f(s[5] - s[6] - s[7], 0.f, INFINITY);
+            }
+            if (mb == NB - 1) wino_store<S, wr, keep, sum>(buf, mb, cob, kq, pend, fc, fz, lsum);
+        }
+        // Issue order inside this K step: after each matrix instruction one patch request for the step
+        // after next, a share of the next step's transform and, where they exist, of the previous
+        // block's stores and the next layer's weight loads.
+        static_for<16>([&](auto xx) {
+            constexpr int x = decltype(xx)::value;
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (c + 2 < NC && x < ND / 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if constexpr (ks == 2 && mb > 0 && wr && x >= 8) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            if constexpr (mb == NB - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            constexpr int nv = (c + 1 < NC ? 2 : 0) + (ks == 2 && mb > 0 ? (FAST ? 1 : 4) : 0) + (c + 2 < NC && x == 0 ? 1 : 0);
+            if constexpr (nv > 0) __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);
+        });
+#pragma unroll
+        for (int x = 0; x < 16; x++) a[x] = an[x];
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(3);
+}
+// the trunk output back from its private copy
+template <int S> __device__ __forceinline__ void wino_restore(float *buf, int lane, float *fc, int fz)
+{
+    using G = Geo<S>;
+    using W = WinoGeo<S>;
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    float unused = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < W::NB; mb++) {
+        float o[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[q][r] = fc[fz + mb * 16 + q * 4 + r];
+        wino_store<S, true, false, false>(buf, mb, (l & 15) * G::PS + G::ROW + 1, l >> 4, o, fc, fz, unused);
+    }
+}
+
+template <int S, bool WINO>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_solo(
     const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val, float *value_out,
     float *logp_out)
@@ -681,18 +979,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     constexpr int NT = G::NT;
     extern __shared__ float lds[];
     float *buf = lds;
-    int *todo = reinterpret_cast<int *>(lds + G::BUF); // [ceil(n / gridDim.x)] positions of this workgroup
+    int *todo = reinterpret_cast<int *>(lds + G::BUF + 64); // [ceil(n / gridDim.x)] positions of this workgroup
     const int lane = threadIdx.x;
     const int co = lane & 15, kq = lane >> 4;
-    for (int i = lane; i < G::BUF; i += 64) buf[i] = 0.f; // halos stay zero from here on
+    for (int i = lane; i < G::BUF + 64; i += 64) buf[i] = 0.f; // halos (and the tail) stay zero from here on
     const int nl = front - 1 + pol + val;
     const float *p_layers = prm + FIRST_FLOATS;
     const float *p_policy = p_layers + (size_t)nl * LAYER_FLOATS;
     const float *p_value = p_policy + POLICY_FLOATS;
+    const float *p_wino = p_value + VALUE_FLOATS;
     // execution order: trunk, value branch, policy branch (parameter order: trunk, policy, value)
     auto layer_params = [&](int e) {
         const int idx = e < front - 1 ? e : (e < front - 1 + val ? e + pol : e - val);
-        return p_layers + (size_t)idx * LAYER_FLOATS;
+        return WINO ? p_wino + (size_t)idx * WINO_FLOATS : p_layers + (size_t)idx * LAYER_FLOATS;
     };
     LayerRegs<5> w0;
     load_layer<5>(prm, lane, w0);
@@ -704,7 +1003,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         off0[ks] = (kk & 1) * G::PS + (tap / 3 - 1) * G::ROW + (tap % 3 - 1);
     }
     SoloMap<S> m;
-    make_solo_map<S>(lane, m);
+    if constexpr (!WINO) make_solo_map<S>(lane, m);
     LayerRegs<4> wp; // policy head as a B operand: B[k = ci][n = tap]
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) wp.b[ks] = co < 9 ? p_policy[co * CH + ks * 4 + kq] : 0.f;
@@ -748,7 +1047,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // value branch owns the buffer (one store and one load per value and position; the
     // register file has no room for a second set of NT tiles).  Indexed through a value the
     // compiler cannot see through, so that the array really lives in memory.
-    float fc[NT * 4 + 1];
+    float fc[WINO ? WinoGeo<S>::NB * 16 : NT * 4 + 1];
     int fz;
     asm volatile("s_mov_b32 %0, 0" : "=s"(fz));
     // pixels this lane loads, gathers and stores: lane, lane + 64, ...
@@ -765,8 +1064,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     };
     if (n_mine > 0) request_board(leaf_kind != nullptr ? todo[0] : (int)blockIdx.x);
     // the weights of the first 16-channel layer: loaded here once, later rolled in by the last layer
-    LayerRegs<36> wq;
-    if (nl > 0) load_layer<36>(layer_params(0), lane, wq);
+    LayerRegs<WINO ? 1 : 36> wq;
+    float u[WINO ? 64 : 1], ush = 0.f;
+    if constexpr (WINO) {
+        if (nl > 0) {
+            load_wino<S>(layer_params(0), lane, u);
+            ush = layer_params(0)[64 * 64 + co];
+        }
+    } else {
+        if (nl > 0) load_layer<36>(layer_params(0), lane, wq);
+    }
     for (int it = 0; it < n_mine; it++) {
         const int pos = leaf_kind != nullptr ? todo[it] : (int)blockIdx.x + it * (int)gridDim.x;
 #ifdef AZ_NET_STAMPS
@@ -788,6 +1095,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         __syncthreads();
         float vsum = 0.f;
         NST(0);
+        if constexpr (WINO) { // (the tile maps of the direct layers are formed when needed: the Winograd layers need the registers)
+            int lo = lane;
+            asm volatile("" : "+v"(lo));
+            make_solo_map<S>(lo, m);
+        }
         // input layer; it is also the trunk's last layer when front == 1
         solo_mma<S, 5, false>(buf, w0, prm, m, off0, lane, w0.sh, acc, cacc);
         NST(6);
@@ -800,27 +1112,51 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const bool last_trunk = e == front - 2;
             const bool last_value = val > 0 && e == front - 1 + val - 1;
             const bool first_policy = pol > 0 && e == front - 1 + val;
-            if (first_policy && val > 0) { // the trunk output comes back from its private copy
-                solo_restore<S>(buf, m, lane, fc, fz);
-                __syncthreads();
-            }
             const float *nextp = layer_params(e + 1 < nl ? e + 1 : 0); // (the last layer fetches the next position's first)
-            const float sh = wq.sh;
-            NST(4);
-            solo_mma<S, 36, true>(buf, wq, nextp, m, off0, lane, sh, acc, cacc);
-            NST(1);
-            wq.sh = nextp[36 * 64 + 16 + co];
-            if (last_value) solo_epilogue<S, EP_SUM>(buf, acc, cacc, sh, m, lane, fc, fz, vsum);
-            else if (last_trunk && val > 0) solo_epilogue<S, EP_WRITE | EP_KEEP>(buf, acc, cacc, sh, m, lane, fc, fz, vsum);
-            else if (last_trunk) solo_epilogue<S, EP_WRITE | EP_SUM>(buf, acc, cacc, sh, m, lane, fc, fz, vsum);
-            else solo_epilogue<S, EP_WRITE>(buf, acc, cacc, sh, m, lane, fc, fz, vsum);
-            __syncthreads();
-            NST(2);
+            if constexpr (WINO) {
+                if (first_policy && val > 0) { // the trunk output comes back from its private copy
+                    wino_restore<S>(buf, lane, fc, fz);
+                    __syncthreads();
+                }
+                const float sh = ush;
+                NST(4);
+                float lsum = 0.f;
+                if (last_value) wino_layer<S, false, false, true>(buf, u, nextp, sh, lane, fc, fz, lsum);
+                else if (last_trunk && val > 0) wino_layer<S, true, true, false>(buf, u, nextp, sh, lane, fc, fz, lsum);
+                else if (last_trunk) wino_layer<S, true, false, true>(buf, u, nextp, sh, lane, fc, fz, lsum);
+                else wino_layer<S, true, false, false>(buf, u, nextp, sh, lane, fc, fz, lsum);
+                if (last_value || (last_trunk && val == 0)) vsum = lsum;
+                ush = nextp[64 * 64 + co];
+                __syncthreads();
+                NST(1);
+            } else {
+                if (first_policy && val > 0) { // the trunk output comes back from its private copy
+                    solo_restore<S>(buf, m, lane, fc, fz);
+                    __syncthreads();
+                }
+                const float sh = wq.sh;
+                NST(4);
+                solo_mma<S, 36, true>(buf, wq, nextp, m, off0, lane, sh, acc, cacc);
+                NST(1);
+                wq.sh = nextp[36 * 64 + 16 + co];
+                if (last_value) solo_epilogue<S, EP_SUM>(buf, acc, cacc, sh, m, lane, fc, fz, vsum);
+                else if (last_trunk && val > 0) solo_epilogue<S, EP_WRITE | EP_KEEP>(buf, acc, cacc, sh, m, lane, fc, fz, vsum);
+                else if (last_trunk) solo_epilogue<S, EP_WRITE | EP_SUM>(buf, acc, cacc, sh, m, lane, fc, fz, vsum);
+                else solo_epilogue<S, EP_WRITE>(buf, acc, cacc, sh, m, lane, fc, fz, vsum);
+                __syncthreads();
+                NST(2);
+            }
         }
         // policy head input: the policy branch's output, or the trunk output when there is no such branch
         if (pol == 0 && val > 0) {
-            solo_restore<S>(buf, m, lane, fc, fz);
+            if constexpr (WINO) wino_restore<S>(buf, lane, fc, fz);
+            else solo_restore<S>(buf, m, lane, fc, fz);
             __syncthreads();
+        }
+        if constexpr (WINO) {
+            int lo = lane;
+            asm volatile("" : "+v"(lo));
+            make_solo_map<S>(lo, m);
         }
         // ---- value head: board average of the 1x1 convolution + bias, tanh
         float vpart = wv * vsum;
@@ -884,7 +1220,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #endif
 }
 
-template <int S> int launch_solo(const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val,
+template <int S, bool WINO> int launch_solo(const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val,
                                  float *value_out, float *logp_out, hipStream_t st)
 {
     using G = Geo<S>;
@@ -895,12 +1231,12 @@ template <int S> int launch_solo(const float *boards, const int *leaf_kind, int 
     const size_t lds_bytes = (size_t)SoloGeo<S>::LDS_BYTES + (size_t)((n + grid - 1) / grid) * sizeof(int);
     static size_t configured[64] = {};
     if (dev < 0 || dev >= 64 || lds_bytes > configured[dev]) {
-        if (hipFuncSetAttribute((const void *)k_net_solo<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) !=
+        if (hipFuncSetAttribute((const void *)k_net_solo<S, WINO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) !=
             hipSuccess)
             return AZ_ERR_HIP;
         if (dev >= 0 && dev < 64) configured[dev] = lds_bytes;
     }
-    hipLaunchKernelGGL(k_net_solo<S>, dim3(grid), dim3(64), lds_bytes, st, boards, leaf_kind, n, prm, front, pol, val, value_out,
+    hipLaunchKernelGGL((k_net_solo<S, WINO>), dim3(grid), dim3(64), lds_bytes, st, boards, leaf_kind, n, prm, front, pol, val, value_out,
                        logp_out);
     return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
 }
@@ -935,7 +1271,8 @@ extern "C" {
 int az_net_param_floats(int front_layers, int policy_layers, int value_layers)
 {
     if (front_layers < 1 || policy_layers < 0 || value_layers < 0) return 0;
-    return FIRST_FLOATS + (front_layers - 1 + policy_layers + value_layers) * LAYER_FLOATS + POLICY_FLOATS + VALUE_FLOATS;
+    return FIRST_FLOATS + (front_layers - 1 + policy_layers + value_layers) * (LAYER_FLOATS + WINO_FLOATS) + POLICY_FLOATS +
+           VALUE_FLOATS;
 }
 
 int az_net_eval(int shape, int n, const float *d_boards, const int *d_leaf_kind, const float *d_params,
@@ -946,12 +1283,16 @@ int az_net_eval(int shape, int n, const float *d_boards, const int *d_leaf_kind,
     if (!d_boards || !d_params || !d_value || !d_logp) return AZ_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     static const bool team = getenv("AZ_NET_TEAM") != nullptr; // tuning override: the multi-wavefront kernel for every shape
+    static const bool wino = getenv("AZ_NET_WINO") != nullptr;
     switch (shape) {
 #define AZ_NET_CASE(s)                                                                                                   \
     case s:                                                                                                              \
+        if (s <= 15 && !team && wino)                                                                                    \
+            return launch_solo<(s <= 15 ? s : 15), true>(d_boards, d_leaf_kind, n, d_params, front_layers,               \
+                                                         policy_layers, value_layers, d_value, d_logp, st);              \
         if (s <= 15 && !team)                                                                                            \
-            return launch_solo<(s <= 15 ? s : 15)>(d_boards, d_leaf_kind, n, d_params, front_layers, policy_layers,      \
-                                                   value_layers, d_value, d_logp, st);                                   \
+            return launch_solo<(s <= 15 ? s : 15), false>(d_boards, d_leaf_kind, n, d_params, front_layers,              \
+                                                          policy_layers, value_layers, d_value, d_logp, st);             \
         return launch<s>(d_boards, d_leaf_kind, n, d_params, front_layers, policy_layers, value_layers, d_value, d_logp, st);
         AZ_NET_CASE(5) AZ_NET_CASE(6) AZ_NET_CASE(7) AZ_NET_CASE(8) AZ_NET_CASE(9) AZ_NET_CASE(10) AZ_NET_CASE(11)
         AZ_NET_CASE(12) AZ_NET_CASE(13) AZ_NET_CASE(14) AZ_NET_CASE(15) AZ_NET_CASE(16) AZ_NET_CASE(17)

@@ -139,6 +139,19 @@ class FusedNetEvaluator:
         out += [wp[0].permute(1, 2, 0).reshape(-1), state["policy.0.bias"].detach().double().cpu().reshape(-1)]
         wv = state["value.0.weight"].detach().double().cpu()   # [1,16,1,1]
         out += [wv.reshape(-1), state["value.0.bias"].detach().double().cpu().reshape(-1)]
+        # The same 16 -> 16 layers in the Winograd F(2x2, 3x3) domain, for the one-wavefront kernel:
+        # U = G g Gt per (output, input) channel pair, stored as the B operand of the matrix
+        # instruction for transformed position x = 4*xi + nu and K step ks: lane (co, kq) holds
+        # U[co, 4*ks + kq, xi, nu]; then the batch-norm shift.
+        gm = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+        for prefix, i in blocks:
+            w, sc, sh = cls._fold(state, prefix, i)
+            uu = gm @ (w * sc.view(-1, 1, 1, 1)) @ gm.T    # [co, ci, 4, 4]
+            b = torch.zeros(16, 4, 64, dtype=torch.float64)
+            for x in range(16):
+                for ks in range(4):
+                    b[x, ks] = uu[co, 4 * ks + kq, x // 4, x % 4]
+            out += [b.reshape(-1), sh]
         return torch.cat(out).to(torch.float32).contiguous(), (front, pol, val)
 
     takes_leaf_kinds = True

@@ -715,6 +715,7 @@ template <int S> struct WinoGeo {
 constexpr int WINO_TAIL = 32;             // zero floats behind the last plane (a patch may reach ROW + 1 floats past it)
 constexpr int WINO_DUMP = WINO_TAIL;      // + ROW + 2 cells that take the stores of tiles outside the board
 constexpr int WINO_FLOATS = 64 * 64 + CH; // U[16 positions][4 K steps][64 lanes], shift[16]
+constexpr int WINO_FIRST_FLOATS = 16 * 64 + CH; // input layer: U[16 positions][64 lanes] (zero for the lanes of K indices 2..3), shift[16]
 
 template <int S> __device__ __forceinline__ void load_wino(const float *prm, int lane, float (&u)[64])
 {
@@ -806,33 +807,43 @@ __device__ __forceinline__ float from_lane_plus_2(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x102 /* row_shl:2 */, 0xf, 0xf, true));
 }
 
-template <int S, bool wr, bool keep, bool sum>
-__device__ __forceinline__ void wino_layer(float *buf, float (&u)[64], const float *nextp, float sh, int lane, float *fc,
+// KS = K steps: 4 for 16 input channels, 1 for the two input planes (K indices 2..3 carry zero weights and
+// read planes 0..1 again).  ROLL: the next layer's weights replace u[] as the last block retires them.
+template <int S, int KS, bool ROLL, bool wr, bool keep, bool sum>
+__device__ __forceinline__ void wino_layer(float *buf, float (&u)[16 * KS], const float *nextp, float sh, int lane, float *fc,
                                            int fz, float &lsum)
 {
     using G = Geo<S>;
     using W = WinoGeo<S>;
-    constexpr int NB = W::NB, NC = NB * 4;
+    constexpr int NB = W::NB, NC = NB * KS;
     constexpr bool FAST = W::TW == 8; // eight tiles per row: neighbouring tiles share half of their patches through DPP
     constexpr int ND = FAST ? 8 : 16; // patch cells a lane loads per K step
+#ifndef AZ_WINO_GRP
+#define AZ_WINO_GRP 16
+#endif
+#ifndef AZ_WINO_PRIO
+#define AZ_WINO_PRIO 3
+#endif
+    constexpr int GRP = AZ_WINO_GRP;  // matrix instructions issued back to back between bursts of vector work
     int l = lane;
     asm volatile("" : "+v"(l)); // (addresses are formed per layer instead of living in registers across the position loop)
     const int kq = l >> 4, co = l & 15;
+    const int kqp = KS == 4 ? kq : (kq & 1); // plane of this lane's K index in K step 0
     const int cob = co * G::PS + G::ROW + 1;
     int pbase[NB];
 #pragma unroll
     for (int mb = 0; mb < NB; mb++) {
         if constexpr (FAST) {
-            pbase[mb] = kq * G::PS + (2 * (2 * mb + (co & 1))) * G::ROW + 2 * (co >> 1);
+            pbase[mb] = kqp * G::PS + (2 * (2 * mb + (co & 1))) * G::ROW + 2 * (co >> 1);
         } else {
             unsigned T = (unsigned)(mb * 16 + co);
             if (W::TILES % 16 != 0) T = T < (unsigned)W::TILES ? T : (unsigned)W::TILES - 1;
             const unsigned ty = (T * W::DIV) >> 16, tx = T - ty * W::TW;
-            pbase[mb] = (int)(kq * G::PS + 2 * ty * G::ROW + 2 * tx);
+            pbase[mb] = (int)(kqp * G::PS + 2 * ty * G::ROW + 2 * tx);
         }
     }
     auto load_patch = [&](int c, float (&d)[ND]) {
-        int po = pbase[c >> 2] + (c & 3) * 4 * G::PS;
+        int po = pbase[c / KS] + (c % KS) * 4 * G::PS;
         asm("" : "+v"(po)); // one address per patch; the cells are immediate offsets (not volatile: a volatile
                             // statement orders every memory access around it and the patches could not be requested early)
         const float *p = buf + po;
@@ -885,11 +896,10 @@ __device__ __forceinline__ void wino_layer(float *buf, float (&u)[64], const flo
     if (NC > 1) load_patch(1, d);
     f32x4 acc[16];
     float pend[4][4];
-    const float *np = nextp + l;
     __builtin_amdgcn_s_setprio(0);
     static_for<NC>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
-        constexpr int mb = c >> 2, ks = c & 3;
+        constexpr int mb = c / KS, ks = c % KS;
         __builtin_amdgcn_sched_barrier(0);
         if (ks == 0) {
 #pragma unroll
@@ -899,24 +909,36 @@ __device__ __forceinline__ void wino_layer(float *buf, float (&u)[64], const flo
             }
         }
         float an[16];
+#ifndef AZ_WINO_PRIO
         if (c + 1 < NC) transform(d, an);
         if (c + 2 < NC) load_patch(c + 2, d);
+#endif
         // (column by column: the inverse transform's column sums can start while the last products run)
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int x = i * 4 + j;
-                acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], u[x * 4 + ks], acc[x], 0, 0, 0);
+                acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], u[x * KS + ks], acc[x], 0, 0, 0);
             }
-        if (mb == NB - 1) { // the next layer's weights replace this layer's as their last use retires
-            const float *p = np + ks * 64;
-            asm("" : "+v"(p));
+#ifdef AZ_WINO_PRIO
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(AZ_WINO_PRIO);
+        if (c + 1 < NC) transform(d, an);
+        if (c + 2 < NC) load_patch(c + 2, d);
+#endif
+        if (ROLL && mb == NB - 1) { // the next layer's weights replace this layer's as their last use retires
+            // (the lane offset passes through an empty statement, the pointer does not: it would lose its address space)
+            // (uniform base + 32-bit byte offset: one offset register for all 16 loads)
+            unsigned o = (unsigned)(l + ks * 64) * 4u;
+            asm("" : "+v"(o));
 #pragma unroll
-            for (int x = 0; x < 16; x++) u[x * 4 + ks] = p[x * 4 * 64];
+            for (int x = 0; x < 16; x++)
+                u[x * KS + ks] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(nextp + x * KS * 64) + o);
         }
-        if (ks == 2 && mb > 0) wino_store<S, wr, keep, sum>(buf, mb - 1, cob, kq, pend, fc, fz, lsum);
-        if (ks == 3) {
+        // (the previous block's outputs: every patch of this block has been requested by now)
+        if (ks == (KS == 4 ? 2 : 0) && mb > 0) wino_store<S, wr, keep, sum>(buf, mb - 1, cob, kq, pend, fc, fz, lsum);
+        if (ks == KS - 1) {
             // (element by element: packed additions cost more issue time next to matrix instructions than two plain ones)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -936,15 +958,21 @@ __device__ __forceinline__ void wino_layer(float *buf, float (&u)[64], const flo
         // Issue order inside this K step: after each matrix instruction one patch request for the step
         // after next, a share of the next step's transform and, where they exist, of the previous
         // block's stores and the next layer's weight loads.
-        static_for<16>([&](auto xx) {
-            constexpr int x = decltype(xx)::value;
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if constexpr (c + 2 < NC && x < ND / 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            if constexpr (ks == 2 && mb > 0 && wr && x >= 8) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            if constexpr (mb == NB - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            constexpr int nv = (c + 1 < NC ? 2 : 0) + (ks == 2 && mb > 0 ? (FAST ? 1 : 4) : 0) + (c + 2 < NC && x == 0 ? 1 : 0);
+#ifdef AZ_WINO_PRIO
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
+#else
+        static_for<16 / GRP>([&](auto xx) {
+            constexpr int x = decltype(xx)::value * GRP;
+            __builtin_amdgcn_sched_group_barrier(0x008, GRP, 0);
+            constexpr int nrd = c + 2 < NC ? ((x + GRP) * (ND / 2) / 16 - x * (ND / 2) / 16) : 0;
+            if constexpr (nrd > 0) __builtin_amdgcn_sched_group_barrier(0x100, nrd, 0);
+            if constexpr (ks == (KS == 4 ? 2 : 0) && mb > 0 && wr && x >= 8) __builtin_amdgcn_sched_group_barrier(0x200, GRP, 0);
+            if constexpr (ROLL && mb == NB - 1) __builtin_amdgcn_sched_group_barrier(0x020, GRP, 0);
+            constexpr int nv = GRP * ((c + 1 < NC ? 2 : 0) + (ks == (KS == 4 ? 2 : 0) && mb > 0 ? (FAST ? 1 : 4) : 0)) + (c + 2 < NC && x == 0 ? 1 : 0);
             if constexpr (nv > 0) __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);
         });
+#endif
 #pragma unroll
         for (int x = 0; x < 16; x++) a[x] = an[x];
     });
@@ -994,7 +1022,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         return WINO ? p_wino + (size_t)idx * WINO_FLOATS : p_layers + (size_t)idx * LAYER_FLOATS;
     };
     LayerRegs<5> w0;
-    load_layer<5>(prm, lane, w0);
+    if constexpr (!WINO) load_layer<5>(prm, lane, w0);
     int off0[5];
 #pragma unroll
     for (int ks = 0; ks < 5; ks++) {
@@ -1066,7 +1094,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // the weights of the first 16-channel layer: loaded here once, later rolled in by the last layer
     LayerRegs<WINO ? 1 : 36> wq;
     float u[WINO ? 64 : 1], ush = 0.f;
+    float u0[WINO ? 16 : 1], u0sh = 0.f; // the input layer in the Winograd domain
     if constexpr (WINO) {
+        const float *p0 = p_wino + (size_t)nl * WINO_FLOATS;
+#pragma unroll
+        for (int x = 0; x < 16; x++) u0[x] = p0[x * 64 + lane];
+        u0sh = p0[16 * 64 + co];
         if (nl > 0) {
             load_wino<S>(layer_params(0), lane, u);
             ush = layer_params(0)[64 * 64 + co];
@@ -1095,19 +1128,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         __syncthreads();
         float vsum = 0.f;
         NST(0);
-        if constexpr (WINO) { // (the tile maps of the direct layers are formed when needed: the Winograd layers need the registers)
-            int lo = lane;
-            asm volatile("" : "+v"(lo));
-            make_solo_map<S>(lo, m);
-        }
         // input layer; it is also the trunk's last layer when front == 1
-        solo_mma<S, 5, false>(buf, w0, prm, m, off0, lane, w0.sh, acc, cacc);
-        NST(6);
-        if (front > 1) solo_epilogue<S, EP_WRITE>(buf, acc, cacc, w0.sh, m, lane, fc, fz, vsum);
-        else if (val > 0) solo_epilogue<S, EP_WRITE | EP_KEEP>(buf, acc, cacc, w0.sh, m, lane, fc, fz, vsum);
-        else solo_epilogue<S, EP_WRITE | EP_SUM>(buf, acc, cacc, w0.sh, m, lane, fc, fz, vsum);
-        __syncthreads();
-        NST(2);
+        if constexpr (WINO) {
+            float lsum = 0.f;
+            if (front > 1) wino_layer<S, 1, false, true, false, false>(buf, u0, nullptr, u0sh, lane, fc, fz, lsum);
+            else if (val > 0) wino_layer<S, 1, false, true, true, false>(buf, u0, nullptr, u0sh, lane, fc, fz, lsum);
+            else wino_layer<S, 1, false, true, false, true>(buf, u0, nullptr, u0sh, lane, fc, fz, lsum);
+            if (front == 1 && val == 0) vsum = lsum;
+            __syncthreads();
+            NST(6);
+        } else {
+            solo_mma<S, 5, false>(buf, w0, prm, m, off0, lane, w0.sh, acc, cacc);
+            NST(6);
+            if (front > 1) solo_epilogue<S, EP_WRITE>(buf, acc, cacc, w0.sh, m, lane, fc, fz, vsum);
+            else if (val > 0) solo_epilogue<S, EP_WRITE | EP_KEEP>(buf, acc, cacc, w0.sh, m, lane, fc, fz, vsum);
+            else solo_epilogue<S, EP_WRITE | EP_SUM>(buf, acc, cacc, w0.sh, m, lane, fc, fz, vsum);
+            __syncthreads();
+            NST(2);
+        }
         for (int e = 0; e < nl; e++) {
             const bool last_trunk = e == front - 2;
             const bool last_value = val > 0 && e == front - 1 + val - 1;
@@ -1121,10 +1159,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const float sh = ush;
                 NST(4);
                 float lsum = 0.f;
-                if (last_value) wino_layer<S, false, false, true>(buf, u, nextp, sh, lane, fc, fz, lsum);
-                else if (last_trunk && val > 0) wino_layer<S, true, true, false>(buf, u, nextp, sh, lane, fc, fz, lsum);
-                else if (last_trunk) wino_layer<S, true, false, true>(buf, u, nextp, sh, lane, fc, fz, lsum);
-                else wino_layer<S, true, false, false>(buf, u, nextp, sh, lane, fc, fz, lsum);
+                if (last_value) wino_layer<S, 4, true, false, false, true>(buf, u, nextp, sh, lane, fc, fz, lsum);
+                else if (last_trunk && val > 0) wino_layer<S, 4, true, true, true, false>(buf, u, nextp, sh, lane, fc, fz, lsum);
+                else if (last_trunk) wino_layer<S, 4, true, true, false, true>(buf, u, nextp, sh, lane, fc, fz, lsum);
+                else wino_layer<S, 4, true, true, false, false>(buf, u, nextp, sh, lane, fc, fz, lsum);
                 if (last_value || (last_trunk && val == 0)) vsum = lsum;
                 ush = nextp[64 * 64 + co];
                 __syncthreads();
@@ -1157,6 +1195,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             int lo = lane;
             asm volatile("" : "+v"(lo));
             make_solo_map<S>(lo, m);
+        }
+        if constexpr (WINO) {
+            // The input layer's weights are fetched again for every position (from an offset the compiler
+            // cannot see through), so that they do not occupy registers during the 16-channel layers.
+            unsigned o = (unsigned)lane * 4u;
+            asm volatile("" : "+v"(o));
+            const char *p0 = reinterpret_cast<const char *>(p_wino + (size_t)nl * WINO_FLOATS);
+#pragma unroll
+            for (int x = 0; x < 16; x++) u0[x] = *reinterpret_cast<const float *>(p0 + x * 256 + o);
         }
         // ---- value head: board average of the 1x1 convolution + bias, tanh
         float vpart = wv * vsum;
@@ -1272,7 +1319,7 @@ int az_net_param_floats(int front_layers, int policy_layers, int value_layers)
 {
     if (front_layers < 1 || policy_layers < 0 || value_layers < 0) return 0;
     return FIRST_FLOATS + (front_layers - 1 + policy_layers + value_layers) * (LAYER_FLOATS + WINO_FLOATS) + POLICY_FLOATS +
-           VALUE_FLOATS;
+           VALUE_FLOATS + WINO_FIRST_FLOATS;
 }
 
 int az_net_eval(int shape, int n, const float *d_boards, const int *d_leaf_kind, const float *d_params,

@@ -152,6 +152,13 @@ class FusedNetEvaluator:
                 for ks in range(4):
                     b[x, ks] = uu[co, 4 * ks + kq, x // 4, x % 4]
             out += [b.reshape(-1), sh]
+        # the input layer in the same form: one K step, K index = input plane, zero for K indices 2..3
+        w, sc, sh = cls._fold(state, "front", 0)
+        uu = gm @ (w * sc.view(-1, 1, 1, 1)) @ gm.T        # [co, 2, 4, 4]
+        b = torch.zeros(16, 64, dtype=torch.float64)
+        for x in range(16):
+            b[x] = torch.where(kq < 2, uu[co, kq & 1, x // 4, x % 4], torch.zeros(64, dtype=torch.float64))
+        out += [b.reshape(-1), sh]
         return torch.cat(out).to(torch.float32).contiguous(), (front, pol, val)
 
     takes_leaf_kinds = True

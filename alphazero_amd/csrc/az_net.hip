@@ -24,6 +24,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <utility>
+#include <atomic>
 
 #include "../../include/azmcts.h"
 
@@ -675,28 +676,35 @@ template <int S> __device__ __forceinline__ void solo_restore(float *buf, const 
 
 
 // ---------------------------------------------------------------------------------
-// Winograd F(2x2, 3x3) form of the 16 -> 16 channel layers for the one-wavefront kernel:
-// a 2x2 block of outputs comes from the 4x4 input patch around it through 16 element-wise
-// products in a transformed domain instead of 36 multiply-adds per output pair, so a layer
-// needs 16 (transformed positions) x 4 (K steps) matrix instructions per 16 tiles: 256 per
-// 15x15 board against 504 for the direct form.
-//   M = 16 tiles of 2x2 outputs (tile T = block*16 + m, row-major over the board's tile grid)
-//   K = 4 input channels, N = the 16 output channels
-//   lane (m, kq) loads the 4x4 patch of ITS tile and channel 4*ks + kq, transforms it in
-//   registers (32 additions: V = Bt d B) and the 16 results ARE its A operands of the 16
-//   matrix instructions of this K step; the B operands are the host-transformed weights
-//   (U = G g Gt, batch-norm scale folded in), 64 registers for a whole layer.
-//   After the fourth K step a lane holds, for each of four tiles, the 16 transformed sums of
-//   its output channel; the inverse transform (24 additions per tile, done on 4-vectors over
-//   the lane's four tiles) gives the 2x2 outputs.  The batch-norm shift enters through the
-//   initial value of the four accumulators that each feed exactly one output.
+// Winograd F(2x2, 3x3) form of the 3x3 layers for the one-wavefront kernel: a 2x2 tile of
+// outputs comes from the 4x4 input patch around it through 16 element-wise products in a
+// transformed domain instead of 36 multiply-adds per output, so a 16 -> 16 channel layer
+// needs 16 (transformed positions) x 4 (K steps) matrix instructions per 16 tiles: 256 for
+// a 15x15 board against 504 in the direct form.
+//   Tile grid: 8 tiles per tile row for every board (tiles past the board's last column are
+//   dummies), two tile rows per block of 16 = the M side of a matrix instruction, lane
+//   m = 2*tx + (ty & 1): horizontally adjacent tiles sit two lanes apart.
+//   K = 4 input channels, N = the 16 output channels.
+//   Lane (m, kq) loads the two left columns of the 4x4 patch of ITS tile and channel
+//   4*ks + kq and forms their column transforms; the two right columns are the left columns
+//   of the tile to the right, whose transforms it takes from two lanes up (DPP, zero behind
+//   the eighth tile: halo).  24 additions give V = Bt d B, the 16 results ARE the lane's A
+//   operands of the 16 matrix instructions of this K step; the B operands are the
+//   host-transformed weights (U = G g Gt, batch-norm scale folded in), 64 registers per layer.
+//   After the last K step a lane holds, for each of four tiles, the 16 transformed sums of
+//   its output channel; the inverse transform (24 additions per tile) gives the 2x2 outputs.
+//   The batch-norm shift enters through the initial value of the four accumulators that
+//   each feed exactly one output.
 // The layer runs in place: the outputs of a block are written one block late, after every
-// patch of the following block has been requested (a block's patches reach one row and one
-// column into its neighbours).  Patches of the last tile row / column read one cell past the
-// halo: that is the next row's halo, the next plane's top halo or the zero tail behind the
-// last plane.
+// patch of the following block has been requested (a block's patches reach one row into its
+// neighbours).  Patches of the last tile row / column read past the halo: that is the next
+// row's halo, the next plane's top halo or the zero tail behind the last plane.
+// Matrix instructions are issued in bursts of 16 with the vector work of a K step behind
+// them at raised priority: vector instructions placed between matrix instructions cost about
+// 2 cycles of matrix time each, after a burst the other wavefront's burst hides them.
+
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression
-// in the body (the scheduling-group builtins only take literals)
+// in the body (the scheduling builtins only take literals)
 template <class F, int... I> __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
 {
     (f(std::integral_constant<int, I>{}), ...);
@@ -707,13 +715,12 @@ template <int N, class F> __device__ __forceinline__ void static_for(F &&f)
 }
 
 template <int S> struct WinoGeo {
-    static constexpr int TW = (S + 1) / 2;       // tiles per board row
-    static constexpr int TILES = TW * TW;
-    static constexpr int NB = (TILES + 15) / 16; // blocks of 16 tiles
-    static constexpr unsigned DIV = 65536 / TW + 1; // T / TW == (T * DIV) >> 16 for T < 64
+    static constexpr int TH = (S + 1) / 2;  // tile rows = real tiles per tile row
+    static constexpr int NB = (TH + 1) / 2; // blocks of two tile rows
+    static_assert(TH <= 8, "eight tiles per tile row");
 };
 constexpr int WINO_TAIL = 32;             // zero floats behind the last plane (a patch may reach ROW + 1 floats past it)
-constexpr int WINO_DUMP = WINO_TAIL;      // + ROW + 2 cells that take the stores of tiles outside the board
+constexpr int WINO_DUMP = WINO_TAIL;      // + ROW + 2 cells that take the stores of dummy tiles
 constexpr int WINO_FLOATS = 64 * 64 + CH; // U[16 positions][4 K steps][64 lanes], shift[16]
 constexpr int WINO_FIRST_FLOATS = 16 * 64 + CH; // input layer: U[16 positions][64 lanes] (zero for the lanes of K indices 2..3), shift[16]
 
@@ -729,69 +736,51 @@ template <int S> __device__ __forceinline__ void load_wino(const float *prm, int
 }
 
 // The 2x2 outputs o[q][r] (q = 2*row + column inside the tile, r = the lane's r-th tile of block
-// mb) of this lane's output channel: cells outside the board (last row / column of an odd board)
-// are replaced by zero and stored all the same, they land on the halo.  `cob` = float offset of
-// the channel's plane + one halo row and column.  wr: store into the buffer; keep: also into the
+// mb: tile column 2*kq + (r >> 1), tile row 2*mb + (r & 1)) of this lane's output channel.
+// Cells outside the board (last row / column of an odd board) are replaced by zero and stored all
+// the same, they land on the halo; dummy tiles store into a dump area.  `cob` = float offset of the
+// channel's plane + one halo row and column.  wr: store into the buffer; keep: also into the
 // private copy; sum: the lane's sum of the stored values is added to lsum.
-// Tile order inside a block of 16: row-major over the board's tile grid, except on boards with
-// eight tiles per row, where m = 2*tx + (ty & 1) (two tile rows per block, horizontally
-// adjacent tiles two lanes apart): every offset below is then a constant on top of one lane value.
 template <int S, bool wr, bool keep, bool sum>
 __device__ __forceinline__ void wino_store(float *buf, int mb, int cob, int kq, float (&o)[4][4], float *fc, int fz, float &lsum)
 {
     using G = Geo<S>;
     using W = WinoGeo<S>;
     constexpr bool ODD = (S & 1) != 0;
-    if constexpr (W::TW == 8) {
-        float *base = buf + cob + 4 * kq; // tile column 2*kq
-        const bool edge = kq == 3;        // tiles r = 2, 3 are the last of their rows
+    const int base = cob + 4 * kq; // tile column 2*kq
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int ty = 2 * mb + (r & 1);
-            const bool below = !ODD || ty != W::TW - 1; // (a constant)
-            if (ODD && r >= 2) {
-                o[1][r] = edge ? 0.f : o[1][r];
-                o[3][r] = edge ? 0.f : o[3][r];
-            }
-            if (!below) o[2][r] = o[3][r] = 0.f;
-            float *c = base + ty * 2 * G::ROW + (r >> 1) * 2;
-            if constexpr (wr) {
-                c[0] = o[0][r];
-                c[1] = o[1][r];
-                if (below) { // (the row below the board is halo and stays zero)
-                    c[G::ROW] = o[2][r];
-                    c[G::ROW + 1] = o[3][r];
-                }
-            }
-            if constexpr (sum) lsum += (o[0][r] + o[1][r]) + (o[2][r] + o[3][r]);
+    for (int r = 0; r < 4; r++) {
+        const int ty = 2 * mb + (r & 1); // (a constant)
+        if (ty >= W::TH) {              // a dummy tile row
+#pragma unroll
+            for (int q = 0; q < 4; q++) o[q][r] = 0.f;
+            continue;
         }
-    } else {
+        const int tx = 2 * kq + (r >> 1);
+        const bool below = !ODD || ty != W::TH - 1; // (a constant)
+        int at = base + ty * 2 * G::ROW + (r >> 1) * 2;
+        if (W::TH < 8 && 6 + (r >> 1) >= W::TH) { // this tile can be a dummy column (kq <= 3)
+            const bool dummy = tx >= W::TH;
+            at = dummy ? G::BUF + WINO_DUMP : at;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const unsigned T = (unsigned)(mb * 16 + r) + 4u * (unsigned)kq;
-            const unsigned ty = (T * W::DIV) >> 16, tx = T - ty * W::TW;
-            int off = cob + (int)(ty * (2 * G::ROW) + tx * 2);
-            const bool valid = W::TILES % 16 == 0 || T < (unsigned)W::TILES;
-            if (ODD) {
-                const bool right = tx != W::TW - 1, below = ty != W::TW - 1;
-                o[1][r] = right ? o[1][r] : 0.f;
-                o[2][r] = below ? o[2][r] : 0.f;
-                o[3][r] = right && below ? o[3][r] : 0.f;
-            }
-            if (!valid) {
-                off = G::BUF + WINO_DUMP;
-#pragma unroll
-                for (int q = 0; q < 4; q++) o[q][r] = 0.f;
-            }
-            if constexpr (wr) {
-                float *c = buf + off;
-                c[0] = o[0][r];
-                c[1] = o[1][r];
+            for (int q = 0; q < 4; q++) o[q][r] = dummy ? 0.f : o[q][r];
+        }
+        if (ODD && 6 + (r >> 1) >= W::TH - 1) { // this tile can be the last of its row
+            const bool last = tx == W::TH - 1;
+            o[1][r] = last ? 0.f : o[1][r];
+            o[3][r] = last ? 0.f : o[3][r];
+        }
+        if (!below) o[2][r] = o[3][r] = 0.f;
+        if constexpr (wr) {
+            float *c = buf + at;
+            c[0] = o[0][r];
+            c[1] = o[1][r];
+            if (below) { // (the row below the board is halo and stays zero)
                 c[G::ROW] = o[2][r];
                 c[G::ROW + 1] = o[3][r];
             }
-            if constexpr (sum) lsum += (o[0][r] + o[1][r]) + (o[2][r] + o[3][r]);
         }
+        if constexpr (sum) lsum += (o[0][r] + o[1][r]) + (o[2][r] + o[3][r]);
     }
     if constexpr (keep) {
 #pragma unroll
@@ -807,6 +796,9 @@ __device__ __forceinline__ float from_lane_plus_2(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x102 /* row_shl:2 */, 0xf, 0xf, true));
 }
 
+#ifndef AZ_WINO_PRIO
+#define AZ_WINO_PRIO 3
+#endif
 // KS = K steps: 4 for 16 input channels, 1 for the two input planes (K indices 2..3 carry zero weights and
 // read planes 0..1 again).  ROLL: the next layer's weights replace u[] as the last block retires them.
 template <int S, int KS, bool ROLL, bool wr, bool keep, bool sum>
@@ -816,91 +808,54 @@ __device__ __forceinline__ void wino_layer(float *buf, float (&u)[16 * KS], cons
     using G = Geo<S>;
     using W = WinoGeo<S>;
     constexpr int NB = W::NB, NC = NB * KS;
-    constexpr bool FAST = W::TW == 8; // eight tiles per row: neighbouring tiles share half of their patches through DPP
-    constexpr int ND = FAST ? 8 : 16; // patch cells a lane loads per K step
-#ifndef AZ_WINO_GRP
-#define AZ_WINO_GRP 16
-#endif
-#ifndef AZ_WINO_PRIO
-#define AZ_WINO_PRIO 3
-#endif
-    constexpr int GRP = AZ_WINO_GRP;  // matrix instructions issued back to back between bursts of vector work
     int l = lane;
     asm volatile("" : "+v"(l)); // (addresses are formed per layer instead of living in registers across the position loop)
     const int kq = l >> 4, co = l & 15;
     const int kqp = KS == 4 ? kq : (kq & 1); // plane of this lane's K index in K step 0
     const int cob = co * G::PS + G::ROW + 1;
-    int pbase[NB];
-#pragma unroll
-    for (int mb = 0; mb < NB; mb++) {
-        if constexpr (FAST) {
-            pbase[mb] = kqp * G::PS + (2 * (2 * mb + (co & 1))) * G::ROW + 2 * (co >> 1);
-        } else {
-            unsigned T = (unsigned)(mb * 16 + co);
-            if (W::TILES % 16 != 0) T = T < (unsigned)W::TILES ? T : (unsigned)W::TILES - 1;
-            const unsigned ty = (T * W::DIV) >> 16, tx = T - ty * W::TW;
-            pbase[mb] = (int)(kqp * G::PS + 2 * ty * G::ROW + 2 * tx);
-        }
-    }
-    auto load_patch = [&](int c, float (&d)[ND]) {
-        int po = pbase[c / KS] + (c % KS) * 4 * G::PS;
+    // top-left cell of the patch of this lane's tile in block 0 (block mb: + 4*mb rows; a dummy tile row reads the last real one again)
+    const int pb0 = kqp * G::PS + 2 * (co & 1) * G::ROW + 2 * (co >> 1);
+    auto load_patch = [&](int c, float (&d)[8]) {
+        const int mb = c / KS;
+        const int rows = (2 * mb + 1 < W::TH) ? 4 * mb * G::ROW : -1; // (only the lanes of the second tile row can be dummies)
+        int po = pb0 + (c % KS) * 4 * G::PS + (rows >= 0 ? rows : (4 * mb - 2 * (co & 1)) * G::ROW);
         asm("" : "+v"(po)); // one address per patch; the cells are immediate offsets (not volatile: a volatile
                             // statement orders every memory access around it and the patches could not be requested early)
         const float *p = buf + po;
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int j = 0; j < ND / 4; j++) d[i * (ND / 4) + j] = p[i * G::ROW + j];
+            for (int j = 0; j < 2; j++) d[i * 2 + j] = p[i * G::ROW + j];
     };
-    auto transform = [&](const float (&d)[ND], float (&a)[16]) {
-        if constexpr (FAST) {
-            // columns 0..1 of the patch are this lane's; columns 2..3 are columns 0..1 of the tile to the
-            // right, whose column sums sit two lanes up (zero behind the last tile of a row: halo)
-            float t[8];
+    auto transform = [&](const float (&d)[8], float (&a)[16]) {
+        float t[8];
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                t[j] = d[j] - d[4 + j];
-                t[2 + j] = d[2 + j] + d[4 + j];
-                t[4 + j] = d[4 + j] - d[2 + j];
-                t[6 + j] = d[2 + j] - d[6 + j];
-            }
+        for (int j = 0; j < 2; j++) {
+            t[j] = d[j] - d[4 + j];
+            t[2 + j] = d[2 + j] + d[4 + j];
+            t[4 + j] = d[4 + j] - d[2 + j];
+            t[6 + j] = d[2 + j] - d[6 + j];
+        }
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const float t2 = from_lane_plus_2(t[i * 2]), t3 = from_lane_plus_2(t[i * 2 + 1]);
-                a[i * 4] = t[i * 2] - t2;
-                a[i * 4 + 1] = t[i * 2 + 1] + t2;
-                a[i * 4 + 2] = t2 - t[i * 2 + 1];
-                a[i * 4 + 3] = t[i * 2 + 1] - t3;
-            }
-        } else {
-            float t[16];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                t[j] = d[j] - d[8 + j];
-                t[4 + j] = d[4 + j] + d[8 + j];
-                t[8 + j] = d[8 + j] - d[4 + j];
-                t[12 + j] = d[4 + j] - d[12 + j];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                a[i * 4] = t[i * 4] - t[i * 4 + 2];
-                a[i * 4 + 1] = t[i * 4 + 1] + t[i * 4 + 2];
-                a[i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1];
-                a[i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
-            }
+        for (int i = 0; i < 4; i++) {
+            const float t2 = from_lane_plus_2(t[i * 2]), t3 = from_lane_plus_2(t[i * 2 + 1]);
+            a[i * 4] = t[i * 2] - t2;
+            a[i * 4 + 1] = t[i * 2 + 1] + t2;
+            a[i * 4 + 2] = t2 - t[i * 2 + 1];
+            a[i * 4 + 3] = t[i * 2 + 1] - t3;
         }
     };
-    float a[16], d[ND];
+    float a[16], d[8];
     load_patch(0, d);
     transform(d, a);
     if (NC > 1) load_patch(1, d);
     f32x4 acc[16];
     float pend[4][4];
-    __builtin_amdgcn_s_setprio(0);
     static_for<NC>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
         constexpr int mb = c / KS, ks = c % KS;
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
         if (ks == 0) {
 #pragma unroll
             for (int x = 0; x < 16; x++) {
@@ -908,11 +863,6 @@ __device__ __forceinline__ void wino_layer(float *buf, float (&u)[16 * KS], cons
                 acc[x] = (f32x4){v, v, v, v};
             }
         }
-        float an[16];
-#ifndef AZ_WINO_PRIO
-        if (c + 1 < NC) transform(d, an);
-        if (c + 2 < NC) load_patch(c + 2, d);
-#endif
         // (column by column: the inverse transform's column sums can start while the last products run)
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -921,14 +871,12 @@ __device__ __forceinline__ void wino_layer(float *buf, float (&u)[16 * KS], cons
                 const int x = i * 4 + j;
                 acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], u[x * KS + ks], acc[x], 0, 0, 0);
             }
-#ifdef AZ_WINO_PRIO
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(AZ_WINO_PRIO);
+        float an[16];
         if (c + 1 < NC) transform(d, an);
         if (c + 2 < NC) load_patch(c + 2, d);
-#endif
         if (ROLL && mb == NB - 1) { // the next layer's weights replace this layer's as their last use retires
-            // (the lane offset passes through an empty statement, the pointer does not: it would lose its address space)
             // (uniform base + 32-bit byte offset: one offset register for all 16 loads)
             unsigned o = (unsigned)(l + ks * 64) * 4u;
             asm("" : "+v"(o));
@@ -955,24 +903,6 @@ __device__ __forceinline__ void wino_layer(float *buf, float (&u)[16 * KS], cons
             }
             if (mb == NB - 1) wino_store<S, wr, keep, sum>(buf, mb, cob, kq, pend, fc, fz, lsum);
         }
-        // Issue order inside this K step: after each matrix instruction one patch request for the step
-        // after next, a share of the next step's transform and, where they exist, of the previous
-        // block's stores and the next layer's weight loads.
-#ifdef AZ_WINO_PRIO
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(0);
-#else
-        static_for<16 / GRP>([&](auto xx) {
-            constexpr int x = decltype(xx)::value * GRP;
-            __builtin_amdgcn_sched_group_barrier(0x008, GRP, 0);
-            constexpr int nrd = c + 2 < NC ? ((x + GRP) * (ND / 2) / 16 - x * (ND / 2) / 16) : 0;
-            if constexpr (nrd > 0) __builtin_amdgcn_sched_group_barrier(0x100, nrd, 0);
-            if constexpr (ks == (KS == 4 ? 2 : 0) && mb > 0 && wr && x >= 8) __builtin_amdgcn_sched_group_barrier(0x200, GRP, 0);
-            if constexpr (ROLL && mb == NB - 1) __builtin_amdgcn_sched_group_barrier(0x020, GRP, 0);
-            constexpr int nv = GRP * ((c + 1 < NC ? 2 : 0) + (ks == (KS == 4 ? 2 : 0) && mb > 0 ? (FAST ? 1 : 4) : 0)) + (c + 2 < NC && x == 0 ? 1 : 0);
-            if constexpr (nv > 0) __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);
-        });
-#endif
 #pragma unroll
         for (int x = 0; x < 16; x++) a[x] = an[x];
     });
@@ -1313,7 +1243,18 @@ template <int S> int launch(const float *boards, const int *leaf_kind, int n, co
 
 } // namespace
 
+// kernel choice of az_net_eval: AZ_NET_FORM_AUTO unless the environment (AZ_NET_FORM=<number>) or
+// az_net_set_form says otherwise
+static std::atomic<int> g_net_form{getenv("AZ_NET_FORM") != nullptr ? atoi(getenv("AZ_NET_FORM")) : AZ_NET_FORM_AUTO};
+
 extern "C" {
+
+int az_net_set_form(int form)
+{
+    if (form < AZ_NET_FORM_AUTO || form > AZ_NET_FORM_TEAM) return AZ_ERR_ARG;
+    g_net_form.store(form, std::memory_order_relaxed);
+    return AZ_OK;
+}
 
 int az_net_param_floats(int front_layers, int policy_layers, int value_layers)
 {
@@ -1329,8 +1270,11 @@ int az_net_eval(int shape, int n, const float *d_boards, const int *d_leaf_kind,
     if (n == 0) return AZ_OK;
     if (!d_boards || !d_params || !d_value || !d_logp) return AZ_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    static const bool team = getenv("AZ_NET_TEAM") != nullptr; // tuning override: the multi-wavefront kernel for every shape
-    static const bool wino = getenv("AZ_NET_WINO") != nullptr;
+    // Boards up to 15x15 take the one-wavefront kernel, in the Winograd form of the 3x3 layers from 12x12
+    // on (fewer matrix instructions than the direct form there); az_net_set_form overrides the choice.
+    const int form = g_net_form.load(std::memory_order_relaxed);
+    const bool team = form == AZ_NET_FORM_TEAM;
+    const bool wino = form == AZ_NET_FORM_WINOGRAD || (form == AZ_NET_FORM_AUTO && shape >= 12);
     switch (shape) {
 #define AZ_NET_CASE(s)                                                                                                   \
     case s:                                                                                                              \

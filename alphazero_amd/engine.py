@@ -65,6 +65,7 @@ SYMBOLS = [
     ("az_fill_noise_dirichlet", _i, [_vp, _i, C.c_ulonglong, _vp]),
     ("az_get_noise_table", _i, [_vp, _vp, _i]),
     ("az_net_param_floats", _i, [_i, _i, _i]),
+    ("az_net_set_form", _i, [_i]),
     ("az_net_eval", _i, [_i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     ("az_aug_key_words", _i, [_i]),
     ("az_aug_rotations", _i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

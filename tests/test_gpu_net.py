@@ -34,17 +34,42 @@ def _boards(n, shape, seed):
     return b.reshape(n, 2, shape, shape)
 
 
+FORMS = {"auto": 0, "direct": 1, "winograd": 2, "team": 3}  # AZ_NET_FORM_* of include/azmcts.h
+
+
+@pytest.fixture
+def net_form():
+    """Selects the kernel az_net_eval runs for the duration of a test."""
+    from alphazero_amd import engine as E
+
+    lib = E.load_library()
+
+    def choose(name):
+        assert lib.az_net_set_form(FORMS[name]) == 0
+
+    yield choose
+    lib.az_net_set_form(FORMS["auto"])
+
+
+@pytest.mark.parametrize("form", ["auto", "direct", "winograd", "team"])
 @pytest.mark.parametrize("shape,front,pol,val,n", [(15, 4, 2, 2, 300), (13, 4, 2, 2, 50), (20, 3, 1, 2, 40),
-                                                     (7, 1, 0, 0, 9), (5, 2, 3, 1, 1100)])
-def test_fused_net_matches_torch_float64(shape, front, pol, val, n):
+                                                     (7, 1, 0, 0, 9), (5, 2, 3, 1, 1100), (14, 2, 0, 1, 70),
+                                                     (12, 1, 1, 0, 33), (10, 3, 1, 1, 20), (6, 2, 1, 1, 5),
+                                                     (11, 1, 0, 2, 64), (9, 2, 2, 0, 130), (8, 3, 0, 0, 17)])
+def test_fused_net_matches_torch_float64(shape, front, pol, val, n, form, net_form):
+    """Every kernel form (one wavefront per position with direct or Winograd 3x3 layers, team of
+    wavefronts) against PyTorch float64, over every branch layout (no policy / value branch, trunk of one)."""
     import torch
     from alphazero_amd.evaluator import FusedNetEvaluator
 
+    if shape > 15 and form in ("direct", "winograd"):
+        pytest.skip("the one-wavefront kernel covers boards up to 15x15")
     m = _model(shape, front, pol, val, 3)
     boards = _boards(n, shape, 5)
     with torch.no_grad():
         v_ref, lp_ref = m.double()(torch.from_numpy(boards).double())
     ev = FusedNetEvaluator(m.float(), shape)
+    net_form(form)
     v, lp = ev(torch.from_numpy(boards).cuda())
     v, lp = v.cpu().numpy(), lp.cpu().numpy()
     assert v.shape == (n,) and lp.shape == (n, shape * shape)

@@ -928,6 +928,76 @@ template <int S> __device__ __forceinline__ void wino_restore(float *buf, int la
     }
 }
 
+// Sum / maximum over the 64 lanes by DPP (quad swaps, mirrors inside rows of 16, then the row
+// totals broadcast upwards); the result is read from lane 63 and is wave-uniform.
+template <bool MAX> __device__ __forceinline__ float wave_reduce(float v)
+{
+    auto step = [&](auto ctrl, auto row_mask) {
+        // lanes outside row_mask receive the identity: 0 for a sum, their own value for a maximum
+        const int old = MAX ? __builtin_bit_cast(int, v) : 0;
+        const float o = __builtin_bit_cast(
+            float, __builtin_amdgcn_update_dpp(old, __builtin_bit_cast(int, v), decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false));
+        v = MAX ? fmaxf(v, o) : v + o;
+    };
+    step(std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{});  // quad_perm:[1,0,3,2]
+    step(std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{});  // quad_perm:[2,3,0,1]
+    step(std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{}); // row_half_mirror
+    step(std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{}); // row_mirror
+    step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{}); // row_bcast:15 into rows 1 and 3
+    step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{}); // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// Policy head, first half: the nine per-tap partial planes (a 1x1 product of the 16 channels
+// with the head's 3x3 weights, tap = output column of the matrix instruction) written over
+// planes 0..8.  M = the cells of one board row (lanes past the row read its right halo cell:
+// zero, so what they store is zero and lands on that halo cell again), so every address is
+// one lane value plus a constant.  All reads precede all writes.
+template <int S> __device__ __forceinline__ void policy_taps_rows(float *buf, const float (&wpb)[4], int lane)
+{
+    using G = Geo<S>;
+    static_assert(S <= 15, "one matrix tile per board row");
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    const int co = l & 15, kq = l >> 4;
+    const float *rd = buf + kq * G::PS + G::ROW + (co < S ? co : S) + 1;
+    f32x4 acc[S];
+    float a[S];
+#pragma unroll
+    for (int t = 0; t < S; t++) {
+        acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        a[t] = rd[t * G::ROW];
+    }
+    __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < S; t++) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], wpb[ks], acc[t], 0, 0, 0);
+            if (ks + 1 < 4) a[t] = rd[(ks + 1) * 4 * G::PS + t * G::ROW];
+        }
+        if (ks + 1 < 4) {
+#pragma unroll
+            for (int t = 0; t < S; t++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(3);
+    if (co < 9) {
+        float *wr[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) wr[r] = buf + co * G::PS + G::ROW + (4 * kq + r < S ? 4 * kq + r : S) + 1;
+#pragma unroll
+        for (int t = 0; t < S; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) wr[r][t * G::ROW] = acc[t][r];
+    }
+}
+
 template <int S, bool WINO>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_solo(
     const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val, float *value_out,
@@ -1122,11 +1192,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             __syncthreads();
         }
         if constexpr (WINO) {
-            int lo = lane;
-            asm volatile("" : "+v"(lo));
-            make_solo_map<S>(lo, m);
-        }
-        if constexpr (WINO) {
             // The input layer's weights are fetched again for every position (from an offset the compiler
             // cannot see through), so that they do not occupy registers during the 16-channel layers.
             unsigned o = (unsigned)lane * 4u;
@@ -1137,13 +1202,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         // ---- value head: board average of the 1x1 convolution + bias, tanh
         float vpart = wv * vsum;
+        if constexpr (WINO) {
+            vpart = wave_reduce<false>(vpart);
+        } else {
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) vpart += __shfl_xor(vpart, o);
+            for (int o = 1; o < 64; o <<= 1) vpart += __shfl_xor(vpart, o);
+        }
         if (lane == 0) value_out[pos] = tanhf(vpart / (float)G::SIZE + v_bias);
         if (it + 1 < n_mine) request_board(leaf_kind != nullptr ? todo[it + 1] : (int)blockIdx.x + (it + 1) * (int)gridDim.x);
         // ---- policy head: per-tap partial planes on the matrix cores, written over the input
-        solo_mma<S, 4, false>(buf, wp, prm, m, off0, lane, 0.f, acc, cacc);
-        if (co < 9) {
+        if constexpr (WINO) policy_taps_rows<S>(buf, wp.b, lane);
+        else solo_mma<S, 4, false>(buf, wp, prm, m, off0, lane, 0.f, acc, cacc);
+        if (!WINO && co < 9) {
 #pragma unroll
             for (int t = 0; t < NT; t++) {
                 const bool partial = G::SIZE % 16 != 0 && !G::CORNER && t == NT - 1;
@@ -1152,7 +1222,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 else store_cells<S, false>(buf, m.wrpk[t], 4, v);
             }
         }
-        if constexpr (G::CORNER) {
+        if constexpr (G::CORNER && !WINO) {
             const float v = sum_over_kq(cacc);
             if (kq == 0 && co < 9) buf[m.cwr] = v;
         }
@@ -1172,13 +1242,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             logit[i] = p < G::SIZE ? s : -INFINITY;
             lmax = fmaxf(lmax, logit[i]);
         }
+        if constexpr (WINO) {
+            lmax = wave_reduce<true>(lmax);
+        } else {
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+            for (int o = 1; o < 64; o <<= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+        }
         float lsum = 0.f;
 #pragma unroll
         for (int i = 0; i < PPL; i++) lsum += lane + 64 * i < G::SIZE ? expf(logit[i] - lmax) : 0.f;
+        if constexpr (WINO) {
+            lsum = wave_reduce<false>(lsum);
+        } else {
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) lsum += __shfl_xor(lsum, o);
+            for (int o = 1; o < 64; o <<= 1) lsum += __shfl_xor(lsum, o);
+        }
         const float lse = lmax + logf(lsum);
 #pragma unroll
         for (int i = 0; i < PPL; i++)

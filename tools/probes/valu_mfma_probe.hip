@@ -10,7 +10,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int NA = 16, REPS = 256;
 
-template <int NV, bool PK, int G>
+template <int NV, bool PK, int G, bool AG = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_probe(float *out, unsigned long long *cyc, int reps)
 {
     const int lane = threadIdx.x;
@@ -28,7 +28,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < NA; t++) {
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], acc[t], 0, 0, 0);
+            if constexpr (AG) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[t]) : "v"(a[t]), "v"(b[t]));
+            else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], acc[t], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < NV; i++) {
                 if (PK) v[i & 7] = v[i & 7] + v[(i + 1) & 7];
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (lane == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <int NV, bool PK, int G = 1> void run(int waves_per_simd)
+template <int NV, bool PK, int G = 1, bool AG = false> void run(int waves_per_simd)
 {
     const int grid = 256 * 4 * waves_per_simd;
     float *out;
@@ -59,9 +60,9 @@ template <int NV, bool PK, int G = 1> void run(int waves_per_simd)
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k_probe<NV, PK, G>), dim3(grid), dim3(64), 0, 0, out, cyc, REPS);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k_probe<NV, PK, G, AG>), dim3(grid), dim3(64), 0, 0, out, cyc, REPS);
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k_probe<NV, PK, G>), dim3(grid), dim3(64), 0, 0, out, cyc, REPS);
+    hipLaunchKernelGGL((k_probe<NV, PK, G, AG>), dim3(grid), dim3(64), 0, 0, out, cyc, REPS);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -69,7 +70,7 @@ template <int NV, bool PK, int G = 1> void run(int waves_per_simd)
     const double mfma_per_wave = (double)REPS * NA;
     const double tflops = (double)grid * mfma_per_wave * 2048.0 / (ms * 1e-3) / 1e12;
     // SIMD time per matrix instruction in ns: ms / (mfma per SIMD)
-    printf("%d %s adds per matrix instruction in groups of %d, %d waves/SIMD: %7.3f ms  %6.1f TFLOP/s  %6.2f ns per matrix instruction per SIMD\n", NV,
+    printf("%s%d %s adds per matrix instruction in groups of %d, %d waves/SIMD: %7.3f ms  %6.1f TFLOP/s  %6.2f ns per matrix instruction per SIMD\n", AG ? "[acc in AGPRs] " : "", NV,
            PK ? "packed" : "plain", G, waves_per_simd, ms, tflops, ms * 1e6 / (mfma_per_wave * waves_per_simd));
     hipFree(out);
     hipFree(cyc);
@@ -92,6 +93,9 @@ int main()
         run<4, false, 16>(w);
         run<2, false, 16>(w);
         run<2, true, 16>(w);
+        run<0, false, 1, true>(w);
+        run<4, false, 1, true>(w);
+        run<4, false, 16, true>(w);
     }
     return 0;
 }

@@ -104,6 +104,65 @@ __device__ __forceinline__ float sum_over_kq(float v)
     return v;
 }
 
+// Which positions a workgroup evaluates: those whose code is AZ_LEAF_EXPAND (a search that ended
+// on a finished game, or an idle tree, needs no evaluation), split evenly over the workgroups in
+// contiguous runs, so the workgroups stay balanced however the skipped ones are spread.  Every
+// workgroup derives its run from the codes by itself (no atomics, no second kernel): each thread
+// counts a slice of the codes (16-byte loads), a prefix sum places the slices, and only the few
+// threads whose slice meets the workgroup's run walk their slice a second time.
+// cnt: LDS scratch of NW ints (unused for a single wavefront).  Returns the length of the run,
+// its positions are in todo[].  Ends with a barrier.
+template <int NTHR> __device__ __forceinline__ int list_positions(const int *leaf_kind, int n, int *todo, int *cnt, int tid)
+{
+    constexpr int NW = NTHR / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int per = (((n + NTHR - 1) / NTHR) + 3) & ~3; // a multiple of four codes per thread
+    const int lo = tid * per, hi = lo + per < n ? lo + per : n;
+    const bool aligned = (reinterpret_cast<uintptr_t>(leaf_kind) & 15) == 0;
+    int c = 0;
+    if (aligned) {
+        int i = lo;
+#pragma unroll 8
+        for (; i + 3 < hi; i += 4) {
+            const int4 v = *reinterpret_cast<const int4 *>(leaf_kind + i);
+            c += (v.x == AZ_LEAF_EXPAND) + (v.y == AZ_LEAF_EXPAND) + (v.z == AZ_LEAF_EXPAND) + (v.w == AZ_LEAF_EXPAND);
+        }
+        for (; i < hi; i++) c += leaf_kind[i] == AZ_LEAF_EXPAND;
+    } else {
+        for (int i = lo; i < hi; i++) c += leaf_kind[i] == AZ_LEAF_EXPAND;
+    }
+    int incl = c; // inclusive prefix over the wavefront, then over the wavefronts
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    int before = incl - c, total;
+    if constexpr (NW > 1) {
+        if (lane == 63) cnt[wave] = incl;
+        __syncthreads();
+        total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            if (w < wave) before += cnt[w];
+            total += cnt[w];
+        }
+    } else {
+        total = __shfl(incl, 63);
+    }
+    const int first = (int)((long long)blockIdx.x * total / (int)gridDim.x);
+    const int last = (int)((long long)(blockIdx.x + 1) * total / (int)gridDim.x); // (exclusive)
+    if (c > 0 && before < last && before + c > first) {
+        for (int i = lo; i < hi && before < last; i++)
+            if (leaf_kind[i] == AZ_LEAF_EXPAND) {
+                if (before >= first) todo[before - first] = i;
+                before++;
+            }
+    }
+    __syncthreads();
+    return last - first;
+}
+
 enum { MODE_WRITE = 0, MODE_VALUE_SUM = 1 };
 
 // What a lane needs to know about the tiles of its wavefront, computed once per
@@ -382,38 +441,11 @@ __global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2,
     const float p_bias = p_policy[9 * CH];
     const float wv = p_value[co], v_bias = p_value[CH];
 
-    // Positions to evaluate: every gridDim.x-th one, counted among those that need an
-    // evaluation (a search that ended on a finished game, or an idle tree, needs
-    // none), so the workgroups stay balanced however the skipped ones are spread.
-    // Every workgroup derives its list from the codes by itself: no atomics, no
-    // second kernel.
+    // Positions to evaluate: this workgroup's share of those that need an evaluation, or every
+    // gridDim.x-th position when no codes are given.
     int n_mine;
     if (leaf_kind != nullptr) {
-        int *cnt = reinterpret_cast<int *>(red); // [NW] per-wavefront totals
-        const int per = (n + G::NTHR - 1) / G::NTHR, lo = tid * per, hi = lo + per < n ? lo + per : n;
-        int c = 0;
-        for (int i = lo; i < hi; i++) c += leaf_kind[i] == AZ_LEAF_EXPAND;
-        int incl = c; // inclusive prefix over the wavefront, then over the wavefronts
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int up = __shfl_up(incl, o);
-            if (lane >= o) incl += up;
-        }
-        if (lane == 63) cnt[wave] = incl;
-        __syncthreads();
-        int before = incl - c, total = 0;
-#pragma unroll
-        for (int w = 0; w < G::NW; w++) {
-            if (w < wave) before += cnt[w];
-            total += cnt[w];
-        }
-        for (int i = lo; i < hi; i++)
-            if (leaf_kind[i] == AZ_LEAF_EXPAND) {
-                if (before % (int)gridDim.x == (int)blockIdx.x) todo[before / (int)gridDim.x] = i;
-                before++;
-            }
-        n_mine = total > (int)blockIdx.x ? (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-        __syncthreads();
+        n_mine = list_positions<G::NTHR>(leaf_kind, n, todo, reinterpret_cast<int *>(red), tid);
     } else {
         n_mine = n > (int)blockIdx.x ? (n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     }
@@ -1041,23 +1073,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
     int n_mine;
     if (leaf_kind != nullptr) {
-        const int per = (n + 63) / 64, lo = lane * per, hi = lo + per < n ? lo + per : n;
-        int c = 0;
-        for (int i = lo; i < hi; i++) c += leaf_kind[i] == AZ_LEAF_EXPAND;
-        int incl = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int up = __shfl_up(incl, o);
-            if (lane >= o) incl += up;
-        }
-        const int total = __shfl(incl, 63);
-        int before = incl - c;
-        for (int i = lo; i < hi; i++)
-            if (leaf_kind[i] == AZ_LEAF_EXPAND) {
-                if (before % (int)gridDim.x == (int)blockIdx.x) todo[before / (int)gridDim.x] = i;
-                before++;
-            }
-        n_mine = total > (int)blockIdx.x ? (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+        n_mine = list_positions<64>(leaf_kind, n, todo, nullptr, lane);
     } else {
         n_mine = n > (int)blockIdx.x ? (n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     }

@@ -210,6 +210,26 @@ def self_play_games(batch0, batch1, sims, tau, init_moves=(), rng=None):
     return out
 
 
+class GameRecords(list):
+    """Per-game record arrays (what the batched self-play drivers return) that are
+    consecutive slices of one array: `flat` is that array, so that writing or gathering
+    all records needs no concatenation."""
+
+    def __init__(self, flat, bounds):
+        super().__init__(flat[bounds[g]:bounds[g + 1]] for g in range(len(bounds) - 1))
+        self.flat = flat
+
+
+def all_records(games):
+    """All records of a list of per-game arrays as one array (no copy when the list
+    came from a batched driver)."""
+    if isinstance(games, GameRecords):
+        return games.flat
+    if isinstance(games, (list, tuple)):
+        return np.concatenate(games) if len(games) else None
+    return games
+
+
 def _assemble_records(torch, dev, slabs, outcome, shape):
     """Training records of many games from per-half-move device slabs, assembled ON THE GPU.
     slabs: list of (step, side, pi [G,SIZE] device, board [G,2,S,S] device, played bool[G],
@@ -243,7 +263,11 @@ def _assemble_records(torch, dev, slabs, outcome, shape):
     out[:, 2 * size:3 * size].copy_(pis.index_select(0, flat))
     del pis
     out[:, 3 * size].copy_(torch.from_numpy(r))
-    rec = out.cpu().numpy().view(dt).reshape(n)
+    # (through page-locked memory: a copy into pageable memory runs at a few GB/s, and the records of a
+    # large batch are gigabytes; the returned array keeps the page-locked tensor alive)
+    host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+    host.copy_(out)
+    rec = host.numpy().view(dt).reshape(n)
     bounds = np.searchsorted(game[order], np.arange(n_games + 1))
     return rec, bounds
 
@@ -302,7 +326,7 @@ def self_play_games_device(batch0, batch1, sims, tau, init_moves=(), rng=None):
         for step, ((pi, board), alive_then) in enumerate(zip(slabs[side], played[side])):
             slab_list.append((step, side, pi, board, alive_then, np.arange(G, dtype=np.int64)))
     rec, bounds = _assemble_records(torch, dev, slab_list, np.asarray(winner, np.float32), S)
-    return [rec[bounds[g]:bounds[g + 1]] for g in range(G)]
+    return GameRecords(rec, bounds)
 
 
 def self_play_stream(batch0, batch1, sims, tau, n_games, init_moves=(), rng=None, flush_plies=None,
@@ -417,7 +441,7 @@ def self_play_stream(batch0, batch1, sims, tau, n_games, init_moves=(), rng=None
     if not rec_parts:  # everything is still on the GPU: order and label the records there
         slab_list = [(step, step & 1, pi, board, played, games) for step, pi, board, played, games in slabs]
         rec, bounds = _assemble_records(torch, dev, slab_list, outcome, S)
-        return [rec[bounds[g]:bounds[g + 1]] for g in range(n_games)]
+        return GameRecords(rec, bounds)
     flush()
     rec = np.concatenate(rec_parts)
     key = np.concatenate(key_parts)
@@ -427,7 +451,7 @@ def self_play_stream(batch0, batch1, sims, tau, n_games, init_moves=(), rng=None
     decided = (won == 0.0) | (won == 1.0)
     rec["r"] = np.where(decided, np.where(won == key[:, 1], 1.0, -1.0), 1e-3).astype(np.float32)
     bounds = np.searchsorted(key[:, 0], np.arange(n_games + 1))
-    return [rec[bounds[g]:bounds[g + 1]] for g in range(n_games)]
+    return GameRecords(rec, bounds)
 
 
 def eval_games(best, latest, sims_best, sims_latest, init_moves=()):
@@ -630,6 +654,6 @@ def reduce_counters(values, group=None):
 def save_samples(path, games):
     """One `.npy` structured array, the file format src/train.py loads
     (np.save at src/self_play.py:111,128)."""
-    data = np.concatenate(games) if isinstance(games, (list, tuple)) else games
+    data = all_records(games)
     np.save(path, data)
     return data

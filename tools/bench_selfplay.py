@@ -79,7 +79,7 @@ def main():
             games = sp.self_play_stream(b0, b1, args.sims, args.tau, n_mine, rng=np.random.default_rng(rank))
         else:
             games = sp.self_play_games_device(b0, b1, args.sims, args.tau, rng=np.random.default_rng(rank))
-        local = np.concatenate(games) if games else np.zeros(0, sp.sample_dtype(args.shape))
+        local = sp.all_records(games) if len(games) else np.zeros(0, sp.sample_dtype(args.shape))
         n_local = len(local)
         samples = sp.gather_samples(local)
         tallies = None

@@ -3,23 +3,23 @@
 // batch 1 at mcts/src/cmcts.cpp:206-231) for ALL leaf positions of a search
 // step in one launch, inference mode (batch-norm folded to scale/shift).
 //
-// gfx950 design.  A small workgroup (two wavefronts at 15x15) owns one position
-// at a time and four such workgroups share a CU, so every SIMD holds two
-// wavefronts of different positions.  The 16-channel activations stay in LDS in
-// TWO plane-major buffers with a zero halo: the trunk and the later layers of a
-// branch run IN PLACE (all tiles of a layer are accumulated in registers, a
-// barrier, then the results overwrite the input), which is what lets four
-// positions fit into the 160 KB of a CU.  HBM sees only the input planes and the
-// outputs.
-// Every 3x3 convolution is an implicit GEMM on the f32-input matrix cores
-// (v_mfma_f32_16x16x4_f32: exact f32 products, f32 accumulate): M = 16 pixels
-// that are consecutive in row-major order over the whole board (tiles cross row
-// ends, so 15x15 = 14 full tiles + one pixel, which a wavefront adds on the
-// vector ALU with the weights it already holds), N = the 16 output channels,
-// K = 4 input channels of one tap.  A wavefront carries all of its tiles (7 at
-// 15x15) as independent accumulators.  The policy head is a 1x1 product on the
-// matrix cores too (16 channels -> 9 per-tap partial planes) followed by a 9-term
-// gather; the value head is summed from the registers of the last value layer.
+// gfx950 design.  The 16-channel activations of a position stay in LDS, plane-major with a
+// zero halo, and every layer runs IN PLACE; HBM sees only the input planes and the outputs.
+// Two kernels:
+//  * k_net_solo (boards up to 15x15): ONE wavefront per position, eight positions per CU, no
+//    barrier.  From 12x12 on the 3x3 layers run in the Winograd F(2x2,3x3) form (16
+//    transformed products per 2x2 output tile instead of 36 multiply-adds per output, 256
+//    instead of 504 matrix instructions per layer at 15x15; see `wino_layer`), below that in
+//    the direct form (`solo_mma`).
+//  * k_net_eval (16x16 - 20x20, where one wavefront cannot hold a board): a team of 2-4
+//    wavefronts per position, two LDS buffers, direct form, one barrier pair per layer.
+// Direct form: every 3x3 convolution is an implicit GEMM on the f32-input matrix cores
+// (v_mfma_f32_16x16x4_f32: exact f32 products, f32 accumulate): M = 16 pixels that are
+// consecutive in row-major order over the whole board (tiles cross row ends, so 15x15 = 14
+// full tiles + one pixel, which a wavefront adds on the vector ALU with the weights it already
+// holds), N = the 16 output channels, K = 4 input channels of one tap.  The policy head is a
+// 1x1 product on the matrix cores too (16 channels -> 9 per-tap partial planes) followed by a
+// 9-term gather; the value head is summed from the registers of the last value layer.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -1291,6 +1291,317 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #endif
 }
 
+// ---------------------------------------------------------------------------------
+// Boards of 16x16 - 20x20 in the Winograd form: a team of four wavefronts per position (the
+// activations of such a board fill 21 - 31 KB, so a CU holds two positions with their two
+// buffers and the eight wavefronts come from teams).  The tile grid is the board's own
+// (ceil(S/2) tiles per row, row-major, blocks of 16), wavefront w takes blocks w and w + 4;
+// every lane loads the whole 4x4 patch of its tile and channel.  A layer that runs in place
+// keeps the outputs of its blocks in registers until every wavefront of the team has read its
+// patches (one barrier), then writes them.
+template <int S> struct WinoTeamGeo {
+    using G = Geo<S>;
+    static constexpr int TW = (S + 1) / 2, TILES = TW * TW, NB = (TILES + 15) / 16;
+    static constexpr int BPW = (NB + G::NW - 1) / G::NW; // blocks a wavefront takes at most
+    static constexpr unsigned DIV = 65536 / TW + 1;       // T / TW == (T * DIV) >> 16 for T < 128
+    static_assert(G::NW == 4 && BPW <= 2 && NB >= G::NW, "four wavefronts, one or two blocks each");
+    static constexpr int TAIL = 32; // zero floats behind the second buffer (a patch may reach ROW + 1 floats past a plane)
+};
+
+// returns the lane's sum of its outputs (MODE_VALUE_SUM; nothing is written then)
+template <int S, int KS, bool ROLL, int MODE, bool INPLACE = false>
+__device__ __forceinline__ float wino_team_layer(const float *src, float *dst, float *dump, float (&u)[16 * KS], const float *nextp,
+                                                 float sh, int wave, int lane)
+{
+    using G = Geo<S>;
+    using W = WinoTeamGeo<S>;
+    constexpr bool ODD = (S & 1) != 0;
+    int l = lane;
+    asm volatile("" : "+v"(l)); // (addresses are formed per layer instead of living in registers across the position loop)
+    const int kq = l >> 4, co = l & 15;
+    const int kqp = KS == 4 ? kq : (kq & 1);
+    const int cob = co * G::PS + G::ROW + 1;
+    const bool two = W::BPW == 2 && wave + G::NW < W::NB; // (wave-uniform) this wavefront has a second block
+    constexpr bool inplace = MODE == MODE_WRITE && INPLACE; // (src == dst)
+    float pend[W::BPW][4][4];
+    float lsum = 0.f;
+    // the outputs of block K of this wavefront: into dst, or added up
+    auto emit = [&](auto kk) {
+        constexpr int K = decltype(kk)::value;
+        const int mb = wave + K * G::NW;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const unsigned T = (unsigned)(mb * 16 + r) + 4u * (unsigned)kq;
+            const unsigned ty = (T * W::DIV) >> 16, tx = T - ty * W::TW;
+            const bool valid = W::TILES % 16 == 0 || T < (unsigned)W::TILES;
+            const bool right = !ODD || tx != W::TW - 1, below = !ODD || ty != W::TW - 1;
+            const float o0 = valid ? pend[K][0][r] : 0.f, o1 = valid && right ? pend[K][1][r] : 0.f;
+            const float o2 = valid && below ? pend[K][2][r] : 0.f, o3 = valid && right && below ? pend[K][3][r] : 0.f;
+            if constexpr (MODE == MODE_WRITE) {
+                // (cells outside an odd board are halo cells: they receive zero; a dummy tile stores into the dump area)
+                float *c = valid ? dst + cob + (int)(ty * (2 * G::ROW) + tx * 2) : dump;
+                c[0] = o0;
+                c[1] = o1;
+                c[G::ROW] = o2;
+                c[G::ROW + 1] = o3;
+            } else {
+                lsum += (o0 + o1) + (o2 + o3);
+            }
+        }
+    };
+    static_for<W::BPW>([&](auto kk) {
+        constexpr int K = decltype(kk)::value;
+        if (K == 1 && !two) return;
+        const bool last = K == 1 || !two; // this wavefront's last block of the layer
+        const int mb = wave + K * G::NW;
+        unsigned T = (unsigned)(mb * 16 + co);
+        T = T < (unsigned)W::TILES ? T : (unsigned)W::TILES - 1; // (a dummy tile reads the last tile again)
+        const unsigned pty = (T * W::DIV) >> 16, ptx = T - pty * W::TW;
+        const int pb = (int)(kqp * G::PS + 2 * pty * G::ROW + 2 * ptx);
+        auto load_patch = [&](int ks, float (&d)[16]) {
+            int po = pb + ks * 4 * G::PS;
+            asm("" : "+v"(po));
+            const float *p = src + po;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) d[i * 4 + j] = p[i * G::ROW + j];
+        };
+        auto transform = [&](const float (&d)[16], float (&a)[16]) {
+            float t[16];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                t[j] = d[j] - d[8 + j];
+                t[4 + j] = d[4 + j] + d[8 + j];
+                t[8 + j] = d[8 + j] - d[4 + j];
+                t[12 + j] = d[4 + j] - d[12 + j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                a[i * 4] = t[i * 4] - t[i * 4 + 2];
+                a[i * 4 + 1] = t[i * 4 + 1] + t[i * 4 + 2];
+                a[i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1];
+                a[i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
+            }
+        };
+        float a[16], d[16];
+        load_patch(0, d);
+        transform(d, a);
+        if (KS > 1) load_patch(1, d);
+        f32x4 acc[16];
+        static_for<KS>([&](auto kss) {
+            constexpr int ks = decltype(kss)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(0);
+            if (ks == 0) {
+#pragma unroll
+                for (int x = 0; x < 16; x++) {
+                    const float v = (x == 0 || x == 15) ? sh : ((x == 3 || x == 12) ? -sh : 0.f);
+                    acc[x] = (f32x4){v, v, v, v};
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int x = i * 4 + j;
+                    acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], u[x * KS + ks], acc[x], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(AZ_WINO_PRIO);
+            float an[16];
+            if (ks + 1 < KS) transform(d, an);
+            if (ks + 2 < KS) load_patch(ks + 2, d);
+            if (ROLL && last) { // the next layer's weights replace this layer's as their last use retires
+                unsigned o = (unsigned)(l + ks * 64) * 4u;
+                asm("" : "+v"(o));
+#pragma unroll
+                for (int x = 0; x < 16; x++)
+                    u[x * KS + ks] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(nextp + x * KS * 64) + o);
+            }
+            if (ks == KS - 1) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float s[8];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        s[j] = acc[j][r] + acc[4 + j][r] + acc[8 + j][r];
+                        s[4 + j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+                    }
+                    pend[K][0][r] = __builtin_amdgcn_fmed3f(s[0] + s[1] + s[2], 0.f, INFINITY);
+                    pend[K][1][r] = __builtin_amdgcn_fmed3f(s[1] - s[2] - s[3], 0.f, INFINITY);
+                    pend[K][2][r] = __builtin_amdgcn_fmed3f(s[4] + s[5] + s[6], 0.f, INFINITY);
+                    pend[K][3][r] = __builtin_amdgcn_fmed3f(s[5] - s[6] - s[7], 0.f, INFINITY);
+                }
+            }
+#pragma unroll
+            for (int x = 0; x < 16; x++) a[x] = an[x];
+        });
+        if (!inplace) emit(kk); // (another buffer, or sums only: nothing to wait for)
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(3);
+    if (inplace) {
+        __syncthreads(); // every wavefront of the team has read its patches
+        static_for<W::BPW>([&](auto kk) {
+            if (decltype(kk)::value == 1 && !two) return;
+            emit(kk);
+        });
+    }
+    return lsum;
+}
+
+template <int S>
+__global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_team_wino(
+    const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val, float *value_out,
+    float *logp_out)
+{
+    using G = Geo<S>;
+    using WG = WinoTeamGeo<S>;
+    extern __shared__ float lds[];
+    float *F = lds, *W = lds + G::BUF;
+    float *red = lds + 2 * G::BUF + WG::TAIL; // [16]: two reduction rows of up to 8 wavefronts
+    float *logit = red + 16;                  // [SIZE]
+    float *dump = red;                        // (stores of dummy tiles: ROW + 2 floats, free while the layers run)
+    int *todo = reinterpret_cast<int *>(logit + G::SIZE); // [ceil(n / gridDim.x)] positions of this workgroup
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co = lane & 15, kq = lane >> 4;
+    for (int i = tid; i < 2 * G::BUF + WG::TAIL; i += G::NTHR) lds[i] = 0.f; // halos and the tail stay zero from here on
+    __syncthreads();
+    const int nl = front - 1 + pol + val;
+    const float *p_policy = prm + FIRST_FLOATS + (size_t)nl * LAYER_FLOATS;
+    const float *p_value = p_policy + POLICY_FLOATS;
+    const float *p_wino = p_value + VALUE_FLOATS;
+    // execution order: trunk, value branch, policy branch (parameter order: trunk, policy, value)
+    auto layer_params = [&](int e) {
+        const int idx = e < front - 1 ? e : (e < front - 1 + val ? e + pol : e - val);
+        return p_wino + (size_t)idx * WINO_FLOATS;
+    };
+    const float *p_first = p_wino + (size_t)nl * WINO_FLOATS;
+    float bp[4]; // policy head as a B operand: B[k = ci][n = tap]
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) bp[ks] = co < 9 ? p_policy[co * CH + ks * 4 + kq] : 0.f;
+    const float p_bias = p_policy[9 * CH];
+    const float wv = p_value[co], v_bias = p_value[CH];
+
+    int n_mine;
+    if (leaf_kind != nullptr) {
+        n_mine = list_positions<G::NTHR>(leaf_kind, n, todo, reinterpret_cast<int *>(red), tid);
+    } else {
+        n_mine = n > (int)blockIdx.x ? (n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    }
+    float u[64], ush = 0.f;
+    if (nl > 0) {
+        load_wino<S>(layer_params(0), lane, u);
+        ush = layer_params(0)[64 * 64 + co];
+    }
+    const float u0sh = p_first[16 * 64 + co];
+    for (int it = 0; it < n_mine; it++) {
+        const int pos = leaf_kind != nullptr ? todo[it] : (int)blockIdx.x + it * (int)gridDim.x;
+        // raw planes into channels 0..1 of W (its other channels may hold interior values of the
+        // previous position: the input layer never reads them)
+        for (int i = tid; i < CIN * G::SIZE; i += G::NTHR) {
+            const int c = i / G::SIZE, p = i - c * G::SIZE;
+            W[c * G::PS + pix_index<S>(p)] = boards[(size_t)pos * CIN * G::SIZE + i];
+        }
+        float u0[16]; // (fetched per position from an offset the compiler cannot see through: no registers held across the layers)
+        {
+            unsigned o = (unsigned)lane * 4u;
+            asm volatile("" : "+v"(o));
+#pragma unroll
+            for (int x = 0; x < 16; x++) u0[x] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(p_first) + x * 256 + o);
+        }
+        __syncthreads();
+        wino_team_layer<S, 1, false, MODE_WRITE>(W, F, dump, u0, nullptr, u0sh, wave, lane);
+        __syncthreads();
+        float vpart = 0.f; // this lane's share of the value head's sum
+        bool v_done = false;
+        // Buffers: a layer writes the buffer it does not read wherever that one is free (no wait between
+        // a wavefront's matrix work and its stores); only the later layers of the value branch run in
+        // place, while the other buffer still holds the trunk output for the policy branch.
+        float *cur = F, *trunk_out = F; // where the latest activations / the trunk output are
+        // without a value branch the head reads the trunk output (before the policy branch reuses its buffer)
+        auto value_from_trunk = [&]() {
+            for (int p = tid; p < G::SIZE; p += G::NTHR) {
+                const int ctr = pix_index<S>(p);
+#pragma unroll
+                for (int ci = 0; ci < CH; ci++) vpart += p_value[ci] * trunk_out[ci * G::PS + ctr];
+            }
+            v_done = true;
+            __syncthreads();
+        };
+        if (val == 0 && front == 1) value_from_trunk();
+        for (int e = 0; e < nl; e++) {
+            const bool trunk = e < front - 1;
+            const bool in_value = !trunk && e < front - 1 + val;
+            const int j = trunk ? 0 : (in_value ? e - (front - 1) : e - (front - 1) - val); // index inside a branch
+            const float *src = (!trunk && j == 0) ? trunk_out : cur;
+            float *other = src == F ? W : F;
+            float *dst = (in_value && j > 0) ? cur : other;
+            const float *nextp = layer_params(e + 1 < nl ? e + 1 : 0); // (the last layer fetches the next position's first)
+            const float sh = ush;
+            if (val > 0 && e == front - 1 + val - 1) {
+                // last layer of the value branch: only the per-channel board sums are needed
+                vpart = wv * wino_team_layer<S, 4, true, MODE_VALUE_SUM>(src, dst, dump, u, nextp, sh, wave, lane);
+                v_done = true;
+            } else {
+                if (src == dst) wino_team_layer<S, 4, true, MODE_WRITE, true>(src, dst, dump, u, nextp, sh, wave, lane);
+                else wino_team_layer<S, 4, true, MODE_WRITE, false>(src, dst, dump, u, nextp, sh, wave, lane);
+            }
+            ush = nextp[64 * 64 + co];
+            cur = dst;
+            if (trunk) trunk_out = dst;
+            __syncthreads();
+            if (val == 0 && e == front - 2) value_from_trunk();
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) vpart += __shfl_xor(vpart, o);
+        // ---- policy head: partial planes on the matrix cores, gather + log-softmax
+        const float *hsrc = pol > 0 ? cur : trunk_out;
+        float *tb = hsrc == F ? W : F;
+        {
+            TileMap<G::TQ + 1> tm; // (formed here: the layers need the registers)
+            int lo = lane;
+            asm volatile("" : "+v"(lo));
+            make_tile_map<S>(wave, lo, tm);
+            policy_taps_layer<S>(hsrc, tb, bp, tm, wave, lane);
+        }
+        if (lane == 0) red[wave] = vpart;
+        __syncthreads();
+        if (tid == 0) { // ---- value head: board average of the 1x1 convolution + bias, tanh
+            float vt = 0.f;
+#pragma unroll
+            for (int w = 0; w < G::NW; w++) vt += red[w];
+            value_out[pos] = tanhf(vt / (float)G::SIZE + v_bias);
+        }
+        __syncthreads(); // red is reused by the softmax
+        policy_softmax<S>(tb, p_bias, red, logit, logp_out + (size_t)pos * G::SIZE, tid, wave, lane);
+        __syncthreads(); // (the dump area overlaps red / logit: the next position's layers wait for the softmax)
+    }
+}
+
+template <int S> int launch_team_wino(const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val,
+                                      float *value_out, float *logp_out, hipStream_t st)
+{
+    using G = Geo<S>;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int grid = cus * G::WGS;
+    if (grid > n) grid = n;
+    const size_t lds_bytes = (size_t)G::FIXED_BYTES + WinoTeamGeo<S>::TAIL * 4 + (size_t)((n + grid - 1) / grid) * sizeof(int);
+    static size_t configured[64] = {};
+    if (dev < 0 || dev >= 64 || lds_bytes > configured[dev]) {
+        if (hipFuncSetAttribute((const void *)k_net_team_wino<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) !=
+            hipSuccess)
+            return AZ_ERR_HIP;
+        if (dev >= 0 && dev < 64) configured[dev] = lds_bytes;
+    }
+    hipLaunchKernelGGL(k_net_team_wino<S>, dim3(grid), dim3(G::NTHR), lds_bytes, st, boards, leaf_kind, n, prm, front, pol, val,
+                       value_out, logp_out);
+    return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
+}
+
 template <int S, bool WINO> int launch_solo(const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val,
                                  float *value_out, float *logp_out, hipStream_t st)
 {
@@ -1365,7 +1676,9 @@ int az_net_eval(int shape, int n, const float *d_boards, const int *d_leaf_kind,
     if (!d_boards || !d_params || !d_value || !d_logp) return AZ_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     // Boards up to 15x15 take the one-wavefront kernel, in the Winograd form of the 3x3 layers from 12x12
-    // on (fewer matrix instructions than the direct form there); az_net_set_form overrides the choice.
+    // on (fewer matrix instructions than the direct form there); larger boards a team of wavefronts per
+    // position, in the Winograd form at 16x16 (measured: one block of tiles per wavefront pays, two with a
+    // barrier between the team's reads and writes do not).  az_net_set_form overrides the choice.
     const int form = g_net_form.load(std::memory_order_relaxed);
     const bool team = form == AZ_NET_FORM_TEAM;
     const bool wino = form == AZ_NET_FORM_WINOGRAD || (form == AZ_NET_FORM_AUTO && shape >= 12);
@@ -1378,6 +1691,9 @@ int az_net_eval(int shape, int n, const float *d_boards, const int *d_leaf_kind,
         if (s <= 15 && !team)                                                                                            \
             return launch_solo<(s <= 15 ? s : 15), false>(d_boards, d_leaf_kind, n, d_params, front_layers,              \
                                                           policy_layers, value_layers, d_value, d_logp, st);             \
+        if (s >= 16 && (form == AZ_NET_FORM_WINOGRAD || (form == AZ_NET_FORM_AUTO && s == 16)))                          \
+            return launch_team_wino<(s >= 16 ? s : 16)>(d_boards, d_leaf_kind, n, d_params, front_layers, policy_layers, \
+                                                       value_layers, d_value, d_logp, st);                              \
         return launch<s>(d_boards, d_leaf_kind, n, d_params, front_layers, policy_layers, value_layers, d_value, d_logp, st);
         AZ_NET_CASE(5) AZ_NET_CASE(6) AZ_NET_CASE(7) AZ_NET_CASE(8) AZ_NET_CASE(9) AZ_NET_CASE(10) AZ_NET_CASE(11)
         AZ_NET_CASE(12) AZ_NET_CASE(13) AZ_NET_CASE(14) AZ_NET_CASE(15) AZ_NET_CASE(16) AZ_NET_CASE(17)

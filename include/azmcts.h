@@ -320,9 +320,10 @@ int az_net_param_floats(int front_layers, int policy_layers, int value_layers);
 /* Which kernel az_net_eval runs (no counterpart in the reference; for tuning and for
  * tests that compare the forms): AUTO = by board size (one wavefront per position up to
  * 15x15, its 3x3 layers in the Winograd F(2x2,3x3) form from 12x12 on; a team of
- * wavefronts per position above 15x15); DIRECT / WINOGRAD = the one-wavefront kernel
- * with that form of the 3x3 layers for every size up to 15x15; TEAM = the team kernel
- * for every size.  Process-wide; initial value from the environment (AZ_NET_FORM). */
+ * wavefronts per position above 15x15, Winograd form at 16x16); DIRECT / WINOGRAD = that
+ * form of the 3x3 layers for every size (one wavefront per position up to 15x15, a team
+ * above; DIRECT above 15x15 is the same as TEAM); TEAM = the direct-form team kernel for
+ * every size.  Process-wide; initial value from the environment (AZ_NET_FORM). */
 enum { AZ_NET_FORM_AUTO = 0, AZ_NET_FORM_DIRECT = 1, AZ_NET_FORM_WINOGRAD = 2, AZ_NET_FORM_TEAM = 3 };
 int az_net_set_form(int form);
 int az_net_eval(int shape, int n, const float *d_boards, const int *d_leaf_kind, const float *d_params,

@@ -55,15 +55,17 @@ def net_form():
 @pytest.mark.parametrize("shape,front,pol,val,n", [(15, 4, 2, 2, 300), (13, 4, 2, 2, 50), (20, 3, 1, 2, 40),
                                                      (7, 1, 0, 0, 9), (5, 2, 3, 1, 1100), (14, 2, 0, 1, 70),
                                                      (12, 1, 1, 0, 33), (10, 3, 1, 1, 20), (6, 2, 1, 1, 5),
-                                                     (11, 1, 0, 2, 64), (9, 2, 2, 0, 130), (8, 3, 0, 0, 17)])
+                                                     (11, 1, 0, 2, 64), (9, 2, 2, 0, 130), (8, 3, 0, 0, 17),
+                                                     (16, 4, 2, 2, 90), (17, 2, 1, 3, 30), (18, 1, 0, 1, 21), (19, 3, 3, 0, 40),
+                                                     (20, 4, 2, 2, 600)])
 def test_fused_net_matches_torch_float64(shape, front, pol, val, n, form, net_form):
     """Every kernel form (one wavefront per position with direct or Winograd 3x3 layers, team of
     wavefronts) against PyTorch float64, over every branch layout (no policy / value branch, trunk of one)."""
     import torch
     from alphazero_amd.evaluator import FusedNetEvaluator
 
-    if shape > 15 and form in ("direct", "winograd"):
-        pytest.skip("the one-wavefront kernel covers boards up to 15x15")
+    if shape > 15 and form == "direct":
+        pytest.skip("above 15x15 the direct form is the team kernel")
     m = _model(shape, front, pol, val, 3)
     boards = _boards(n, shape, 5)
     with torch.no_grad():

@@ -1581,6 +1581,403 @@ __global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2,
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Winograd form with ONE wavefront per SIMD (four positions per CU): a wavefront alone on a
+// SIMD owns the whole register file (512 registers), so
+//  * the 16 transformed accumulators exist twice: the matrix instructions of block b+1 are
+//    issued before the inverse transform of block b, which then runs from the other set while
+//    the matrix cores work (the matrix instructions of a wavefront and its own vector
+//    instructions overlap as long as they do not depend on each other);
+//  * the trunk output waits in registers, not in private memory, while the value branch owns
+//    the buffer;
+//  * a single in-place LDS buffer per position is enough for every board up to 20x20.
+// Tile grid: the board's own (ceil(S/2) tiles per tile row), row-major, blocks of 16 tiles =
+// the M side of a matrix instruction; a lane loads the whole 4x4 patch of its tile and channel.
+// In place: the outputs of block b are stored once every patch of block b+1 has been requested
+// (a patch reaches one row and one column into the neighbouring tiles, i.e. at most
+// ceil(S/2) + 1 <= 16 tiles back).
+template <int S> struct WideGeo {
+    using G = Geo<S>;
+    static constexpr int TW = (S + 1) / 2, TILES = TW * TW, NB = (TILES + 15) / 16;
+    static constexpr unsigned DIV = 65536 / TW + 1; // T / TW == (T * DIV) >> 16 for T < 128
+    static constexpr int LDS_BYTES = (G::BUF + 64) * 4; // + the zero tail and the dump cells
+    static constexpr int WGS = 4;
+    static constexpr int TPR = (S + 15) / 16; // matrix tiles per board row (policy head)
+    static_assert(TW + 1 <= 16 && NB * 16 < 128 + 16, "tile grid");
+    static_assert(WGS * (LDS_BYTES + 512) <= 160 * 1024, "four positions per CU");
+};
+
+// Stores (wr), adds up (sum) or parks (keep) the outputs o[q][r] of block mb: q = 2*row + column inside
+// the 2x2 tile, r = the lane's r-th tile (tile 16*mb + 4*kq + r), channel co.  Cells outside an odd board
+// are halo cells and receive zero; tiles past the grid store into the dump cells.
+template <int S, bool wr, bool keep, bool sum>
+__device__ __forceinline__ void wide_emit(float *buf, int mb, int cob, int kq, float (&o)[4][4], float (&fc)[WideGeo<S>::NB * 16],
+                                          float &lsum)
+{
+    using G = Geo<S>;
+    using W = WideGeo<S>;
+    constexpr bool ODD = (S & 1) != 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const unsigned T = (unsigned)(mb * 16 + r) + 4u * (unsigned)kq;
+        const unsigned ty = (T * W::DIV) >> 16, tx = T - ty * W::TW;
+        const bool valid = (mb + 1) * 16 <= W::TILES || T < (unsigned)W::TILES;
+        const bool right = !ODD || tx != W::TW - 1, below = !ODD || ty != W::TW - 1;
+        o[0][r] = valid ? o[0][r] : 0.f;
+        o[1][r] = valid && right ? o[1][r] : 0.f;
+        o[2][r] = valid && below ? o[2][r] : 0.f;
+        o[3][r] = valid && right && below ? o[3][r] : 0.f;
+        if constexpr (wr) {
+            float *c = buf + (valid ? cob + (int)(ty * (2 * G::ROW) + tx * 2) : G::BUF + WINO_DUMP);
+            c[0] = o[0][r];
+            c[1] = o[1][r];
+            c[G::ROW] = o[2][r];
+            c[G::ROW + 1] = o[3][r];
+        }
+        if constexpr (sum) lsum += (o[0][r] + o[1][r]) + (o[2][r] + o[3][r]);
+        if constexpr (keep) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) fc[mb * 16 + q * 4 + r] = o[q][r];
+        }
+    }
+}
+
+// KS = K steps: 4 for 16 input channels, 1 for the two input planes (K indices 2..3 carry zero weights and
+// read planes 0..1 again).  ROLL: the next layer's weights replace u[] as the last block retires them.
+template <int S, int KS, bool ROLL, bool wr, bool keep, bool sum>
+__device__ __forceinline__ void wide_layer(float *buf, float (&u)[16 * KS], const float *nextp, float sh, int lane,
+                                           float (&fc)[WideGeo<S>::NB * 16], float &lsum)
+{
+    using G = Geo<S>;
+    using W = WideGeo<S>;
+    constexpr int NB = W::NB, NC = NB * KS;
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    const int kq = l >> 4, co = l & 15;
+    const int kqp = KS == 4 ? kq : (kq & 1); // plane of this lane's K index in K step 0
+    const int cob = co * G::PS + G::ROW + 1;
+    auto load_patch = [&](int c, float (&d)[16]) {
+        const int mb = c / KS;
+        unsigned T = (unsigned)(mb * 16) + (unsigned)co;
+        if ((mb + 1) * 16 > W::TILES) T = T < (unsigned)W::TILES ? T : (unsigned)W::TILES - 1; // (a dummy tile reads the last tile again)
+        const unsigned ty = (T * W::DIV) >> 16, tx = T - ty * W::TW;
+        int po = (int)(kqp * G::PS + 2 * ty * G::ROW + 2 * tx) + (c % KS) * 4 * G::PS;
+        asm("" : "+v"(po)); // one address per patch; the cells are immediate offsets
+        const float *p = buf + po;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) d[i * 4 + j] = p[i * G::ROW + j];
+    };
+    auto transform = [&](const float (&d)[16], float (&a)[16]) { // Bt d B
+        float t[16];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            t[j] = d[j] - d[8 + j];
+            t[4 + j] = d[4 + j] + d[8 + j];
+            t[8 + j] = d[8 + j] - d[4 + j];
+            t[12 + j] = d[4 + j] - d[12 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            a[i * 4] = t[i * 4] - t[i * 4 + 2];
+            a[i * 4 + 1] = t[i * 4 + 1] + t[i * 4 + 2];
+            a[i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1];
+            a[i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
+        }
+    };
+    // At Y A of the accumulators' components r0..r1, ReLU
+    auto inverse = [&](const f32x4 (&acc)[16], float (&o)[4][4], int r0, int r1) {
+#pragma unroll
+        for (int r = r0; r < r1; r++) {
+            float s[8];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                s[j] = acc[j][r] + acc[4 + j][r] + acc[8 + j][r];
+                s[4 + j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+            }
+            o[0][r] = __builtin_amdgcn_fmed3f(s[0] + s[1] + s[2], 0.f, INFINITY);
+            o[1][r] = __builtin_amdgcn_fmed3f(s[1] - s[2] - s[3], 0.f, INFINITY);
+            o[2][r] = __builtin_amdgcn_fmed3f(s[4] + s[5] + s[6], 0.f, INFINITY);
+            o[3][r] = __builtin_amdgcn_fmed3f(s[5] - s[6] - s[7], 0.f, INFINITY);
+        }
+    };
+    float a[16], d[16];
+    load_patch(0, d);
+    transform(d, a);
+    if (NC > 1) load_patch(1, d);
+    // The batch-norm shift enters through the C operand of a block's first matrix instructions: the four
+    // accumulators that each feed exactly one of the 2x2 outputs start from +-shift, the others from zero.
+    const f32x4 shp = (f32x4){sh, sh, sh, sh}, shn = (f32x4){-sh, -sh, -sh, -sh}, zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2][16]; // the accumulators of the block in flight and of the block before it
+    float pend[4][4];
+    static_for<NC>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        constexpr int mb = c / KS, ks = c % KS, cur = mb & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int x = i * 4 + j;
+                if (ks == 0)
+                    acc[cur][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], u[x * KS + ks],
+                                                                       (x == 0 || x == 15) ? shp : ((x == 3 || x == 12) ? shn : zero), 0, 0, 0);
+                else acc[cur][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[x], u[x * KS + ks], acc[cur][x], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(AZ_WINO_PRIO);
+        // ---- vector work in the shadow of the matrix instructions just issued (none of it reads acc[cur])
+        float an[16];
+        if (c + 1 < NC) transform(d, an);
+        if (c + 2 < NC) load_patch(c + 2, d);
+        if (ROLL && mb == NB - 1) { // the next layer's weights replace this layer's as their last use retires
+            unsigned o = (unsigned)(l + ks * 64) * 4u;
+            asm("" : "+v"(o));
+#pragma unroll
+            for (int x = 0; x < 16; x++)
+                u[x * KS + ks] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(nextp + x * KS * 64) + o);
+        }
+        if (mb > 0) { // the block before: inverse transform over the first K steps, then its stores
+            if constexpr (KS == 4) {
+                if (ks == 0) inverse(acc[cur ^ 1], pend, 0, 2);
+                if (ks == 1) inverse(acc[cur ^ 1], pend, 2, 4);
+                // (every patch of this block has been requested by the end of K step 1)
+                if (ks == 2) wide_emit<S, wr, keep, sum>(buf, mb - 1, cob, kq, pend, fc, lsum);
+            } else {
+                inverse(acc[cur ^ 1], pend, 0, 4);
+                wide_emit<S, wr, keep, sum>(buf, mb - 1, cob, kq, pend, fc, lsum);
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 16; x++) a[x] = an[x];
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(3);
+    inverse(acc[(NB - 1) & 1], pend, 0, 4);
+    wide_emit<S, wr, keep, sum>(buf, NB - 1, cob, kq, pend, fc, lsum);
+}
+
+// the trunk output back from the registers it was parked in
+template <int S> __device__ __forceinline__ void wide_restore(float *buf, int lane, float (&fc)[WideGeo<S>::NB * 16])
+{
+    using G = Geo<S>;
+    using W = WideGeo<S>;
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    float unused = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < W::NB; mb++) {
+        float o[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[q][r] = fc[mb * 16 + q * 4 + r];
+        wide_emit<S, true, false, false>(buf, mb, (l & 15) * G::PS + G::ROW + 1, l >> 4, o, fc, unused);
+    }
+}
+
+// Policy head, first half, for any board: the nine per-tap partial planes written over planes 0..8.
+// M = 16 cells of one board row (two tiles per row above 16 cells; lanes past the row end read its right
+// halo cell, zero, and what they store is zero and lands on that cell again).  A cell's product reads and
+// writes that cell only, so the rows go in groups: all reads of a group precede its writes.
+template <int S> __device__ __forceinline__ void policy_taps_wide(float *buf, const float (&wpb)[4], int lane)
+{
+    using G = Geo<S>;
+    constexpr int TPR = WideGeo<S>::TPR, RG = 5, NG = (S + RG - 1) / RG; // RG board rows per group
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    const int co = l & 15, kq = l >> 4;
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        const int rows = (g + 1) * RG <= S ? RG : S - g * RG;
+        f32x4 acc[RG * TPR];
+#pragma unroll
+        for (int t = 0; t < RG * TPR; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+            for (int t = 0; t < RG * TPR; t++) {
+                if (t / TPR >= rows) continue;
+                const int cell = co + 16 * (t % TPR);
+                const float av = buf[(ks * 4 + kq) * G::PS + (g * RG + t / TPR + 1) * G::ROW + (cell < S ? cell : S) + 1];
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wpb[ks], acc[t], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(3);
+        if (co < 9) {
+#pragma unroll
+            for (int t = 0; t < RG * TPR; t++) {
+                if (t / TPR >= rows) continue;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int cell = 4 * kq + r + 16 * (t % TPR);
+                    buf[co * G::PS + (g * RG + t / TPR + 1) * G::ROW + (cell < S ? cell : S) + 1] = acc[t][r];
+                }
+            }
+        }
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_net_wide(
+    const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val, float *value_out,
+    float *logp_out)
+{
+    using G = Geo<S>;
+    using W = WideGeo<S>;
+    extern __shared__ float lds[];
+    float *buf = lds;
+    int *todo = reinterpret_cast<int *>(lds + G::BUF + 64); // [ceil(n / gridDim.x)] positions of this workgroup
+    const int lane = threadIdx.x;
+    const int co = lane & 15, kq = lane >> 4;
+    for (int i = lane; i < G::BUF + 64; i += 64) buf[i] = 0.f; // halos (and the tail) stay zero from here on
+    const int nl = front - 1 + pol + val;
+    const float *p_policy = prm + FIRST_FLOATS + (size_t)nl * LAYER_FLOATS;
+    const float *p_value = p_policy + POLICY_FLOATS;
+    const float *p_wino = p_value + VALUE_FLOATS;
+    // execution order: trunk, value branch, policy branch (parameter order: trunk, policy, value)
+    auto layer_params = [&](int e) {
+        const int idx = e < front - 1 ? e : (e < front - 1 + val ? e + pol : e - val);
+        return p_wino + (size_t)idx * WINO_FLOATS;
+    };
+    const float *p_first = p_wino + (size_t)nl * WINO_FLOATS;
+    float wpb[4]; // policy head as a B operand: B[k = ci][n = tap]
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) wpb[ks] = co < 9 ? p_policy[co * CH + ks * 4 + kq] : 0.f;
+    const float p_bias = p_policy[9 * CH];
+    const float wv = p_value[co], v_bias = p_value[CH];
+
+    int n_mine;
+    if (leaf_kind != nullptr) {
+        n_mine = list_positions<64>(leaf_kind, n, todo, nullptr, lane);
+    } else {
+        n_mine = n > (int)blockIdx.x ? (n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    }
+    __syncthreads(); // (a single wavefront: orders the LDS traffic)
+
+    float fc[W::NB * 16]; // the trunk output while the value branch owns the buffer
+#pragma unroll
+    for (int i = 0; i < W::NB * 16; i++) fc[i] = 0.f;
+    constexpr int PPL = (G::SIZE + 63) / 64; // pixels this lane loads, gathers and stores: lane, lane + 64, ...
+    float in0[PPL], in1[PPL];                // the next position's input planes, requested one position ahead
+    auto request_board = [&](int pos) {
+        const float *bp = boards + (size_t)pos * CIN * G::SIZE;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) {
+            const int p = lane + 64 * i;
+            in0[i] = p < G::SIZE ? bp[p] : 0.f;
+            in1[i] = p < G::SIZE ? bp[G::SIZE + p] : 0.f;
+        }
+    };
+    if (n_mine > 0) request_board(leaf_kind != nullptr ? todo[0] : (int)blockIdx.x);
+    float u[64], ush = 0.f; // the weights of the first 16-channel layer: loaded here once, later rolled in by the last layer
+    float u0[16];           // the input layer
+#pragma unroll
+    for (int x = 0; x < 16; x++) u0[x] = p_first[x * 64 + lane];
+    const float u0sh = p_first[16 * 64 + co];
+    if (nl > 0) {
+        load_wino<S>(layer_params(0), lane, u);
+        ush = layer_params(0)[64 * 64 + co];
+    }
+    for (int it = 0; it < n_mine; it++) {
+        const int pos = leaf_kind != nullptr ? todo[it] : (int)blockIdx.x + it * (int)gridDim.x;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) { // the two input planes (requested while the previous position was in its heads)
+            const int p = lane + 64 * i;
+            if (p < G::SIZE) {
+                const int ctr = pix_index<S>(p);
+                buf[ctr] = in0[i];
+                buf[G::PS + ctr] = in1[i];
+            }
+        }
+        __syncthreads();
+        float vsum = 0.f, lsum = 0.f;
+        // input layer; it is also the trunk's last layer when front == 1
+        if (front > 1) wide_layer<S, 1, false, true, false, false>(buf, u0, nullptr, u0sh, lane, fc, lsum);
+        else if (val > 0) wide_layer<S, 1, false, true, true, false>(buf, u0, nullptr, u0sh, lane, fc, lsum);
+        else wide_layer<S, 1, false, true, false, true>(buf, u0, nullptr, u0sh, lane, fc, lsum);
+        if (front == 1 && val == 0) vsum = lsum;
+        __syncthreads();
+        for (int e = 0; e < nl; e++) {
+            const bool last_trunk = e == front - 2;
+            const bool last_value = val > 0 && e == front - 1 + val - 1;
+            const bool first_policy = pol > 0 && e == front - 1 + val;
+            const float *nextp = layer_params(e + 1 < nl ? e + 1 : 0); // (the last layer fetches the next position's first)
+            if (first_policy && val > 0) { // the trunk output comes back
+                wide_restore<S>(buf, lane, fc);
+                __syncthreads();
+            }
+            const float sh = ush;
+            lsum = 0.f;
+            if (last_value) wide_layer<S, 4, true, false, false, true>(buf, u, nextp, sh, lane, fc, lsum);
+            else if (last_trunk && val > 0) wide_layer<S, 4, true, true, true, false>(buf, u, nextp, sh, lane, fc, lsum);
+            else if (last_trunk) wide_layer<S, 4, true, true, false, true>(buf, u, nextp, sh, lane, fc, lsum);
+            else wide_layer<S, 4, true, true, false, false>(buf, u, nextp, sh, lane, fc, lsum);
+            if (last_value || (last_trunk && val == 0)) vsum = lsum;
+            ush = nextp[64 * 64 + co];
+            __syncthreads();
+        }
+        // policy head input: the policy branch's output, or the trunk output when there is no such branch
+        if (pol == 0 && val > 0) {
+            wide_restore<S>(buf, lane, fc);
+            __syncthreads();
+        }
+        // ---- value head: board average of the 1x1 convolution + bias, tanh
+        const float vpart = wave_reduce<false>(wv * vsum);
+        if (lane == 0) value_out[pos] = tanhf(vpart / (float)G::SIZE + v_bias);
+        if (it + 1 < n_mine) request_board(leaf_kind != nullptr ? todo[it + 1] : (int)blockIdx.x + (it + 1) * (int)gridDim.x);
+        // ---- policy head: per-tap partial planes on the matrix cores, written over the input
+        policy_taps_wide<S>(buf, wpb, lane);
+        __syncthreads();
+        // gather of the nine planes + bias, log-softmax over the board
+        float logit[PPL];
+        float lmax = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) {
+            const int p = lane + 64 * i;
+            const int ctr = pix_index<S>(p < G::SIZE ? p : 0);
+            float s = p_bias;
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) s += buf[tap * G::PS + ctr + (tap / 3 - 1) * G::ROW + (tap % 3 - 1)];
+            logit[i] = p < G::SIZE ? s : -INFINITY;
+            lmax = fmaxf(lmax, logit[i]);
+        }
+        lmax = wave_reduce<true>(lmax);
+        float esum = 0.f;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) esum += lane + 64 * i < G::SIZE ? expf(logit[i] - lmax) : 0.f;
+        esum = wave_reduce<false>(esum);
+        const float lse = lmax + logf(esum);
+#pragma unroll
+        for (int i = 0; i < PPL; i++)
+            if (lane + 64 * i < G::SIZE) logp_out[(size_t)pos * G::SIZE + lane + 64 * i] = logit[i] - lse;
+        __syncthreads(); // the gather is over before the next position's input lands in the buffer
+        // planes 2..15 keep leftovers (partial planes, old activations): the input layer reads planes 0..1 only
+    }
+}
+
+template <int S> int launch_wide(const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val,
+                                 float *value_out, float *logp_out, hipStream_t st)
+{
+    using W = WideGeo<S>;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int grid = cus * W::WGS;
+    if (grid > n) grid = n;
+    const size_t lds_bytes = (size_t)W::LDS_BYTES + (size_t)((n + grid - 1) / grid) * sizeof(int);
+    static size_t configured[64] = {};
+    if (dev < 0 || dev >= 64 || lds_bytes > configured[dev]) {
+        if (hipFuncSetAttribute((const void *)k_net_wide<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return AZ_ERR_HIP;
+        if (dev >= 0 && dev < 64) configured[dev] = lds_bytes;
+    }
+    hipLaunchKernelGGL(k_net_wide<S>, dim3(grid), dim3(64), lds_bytes, st, boards, leaf_kind, n, prm, front, pol, val, value_out,
+                       logp_out);
+    return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
+}
+
 template <int S> int launch_team_wino(const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val,
                                       float *value_out, float *logp_out, hipStream_t st)
 {
@@ -1608,7 +2005,8 @@ template <int S, bool WINO> int launch_solo(const float *boards, const int *leaf
     using G = Geo<S>;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    int grid = cus * SoloGeo<S>::WGS;
+    static const int wgs_override = getenv("AZ_NET_SOLO_WGS") != nullptr ? atoi(getenv("AZ_NET_SOLO_WGS")) : 0; // (experiments)
+    int grid = cus * (wgs_override > 0 ? wgs_override : SoloGeo<S>::WGS);
     if (grid > n) grid = n;
     const size_t lds_bytes = (size_t)SoloGeo<S>::LDS_BYTES + (size_t)((n + grid - 1) / grid) * sizeof(int);
     static size_t configured[64] = {};
@@ -1656,7 +2054,7 @@ extern "C" {
 
 int az_net_set_form(int form)
 {
-    if (form < AZ_NET_FORM_AUTO || form > AZ_NET_FORM_TEAM) return AZ_ERR_ARG;
+    if (form < AZ_NET_FORM_AUTO || form > AZ_NET_FORM_WIDE) return AZ_ERR_ARG;
     g_net_form.store(form, std::memory_order_relaxed);
     return AZ_OK;
 }
@@ -1675,29 +2073,36 @@ int az_net_eval(int shape, int n, const float *d_boards, const int *d_leaf_kind,
     if (n == 0) return AZ_OK;
     if (!d_boards || !d_params || !d_value || !d_logp) return AZ_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    // Boards up to 15x15 take the one-wavefront kernel, in the Winograd form of the 3x3 layers from 12x12
-    // on (fewer matrix instructions than the direct form there); larger boards a team of wavefronts per
-    // position, in the Winograd form at 16x16 (measured: one block of tiles per wavefront pays, two with a
-    // barrier between the team's reads and writes do not).  az_net_set_form overrides the choice.
+    // Boards up to 15x15 take the one-wavefront-per-position kernel with two wavefronts per SIMD, in the
+    // Winograd form of the 3x3 layers from 12x12 on (fewer matrix instructions than the direct form there);
+    // larger boards the Winograd kernel with one wavefront per SIMD (k_net_wide: measured faster than both
+    // team kernels at every size from 16x16 to 20x20).  az_net_set_form overrides the choice.
     const int form = g_net_form.load(std::memory_order_relaxed);
     const bool team = form == AZ_NET_FORM_TEAM;
     const bool wino = form == AZ_NET_FORM_WINOGRAD || (form == AZ_NET_FORM_AUTO && shape >= 12);
     switch (shape) {
 #define AZ_NET_CASE(s)                                                                                                   \
     case s:                                                                                                              \
+        if (s >= 12 && (form == AZ_NET_FORM_WIDE || (form == AZ_NET_FORM_AUTO && s >= 16)))                              \
+            return launch_wide<(s >= 12 ? s : 12)>(d_boards, d_leaf_kind, n, d_params, front_layers, policy_layers,      \
+                                                   value_layers, d_value, d_logp, st);                                   \
         if (s <= 15 && !team && wino)                                                                                    \
             return launch_solo<(s <= 15 ? s : 15), true>(d_boards, d_leaf_kind, n, d_params, front_layers,               \
                                                          policy_layers, value_layers, d_value, d_logp, st);              \
         if (s <= 15 && !team)                                                                                            \
             return launch_solo<(s <= 15 ? s : 15), false>(d_boards, d_leaf_kind, n, d_params, front_layers,              \
                                                           policy_layers, value_layers, d_value, d_logp, st);             \
-        if (s >= 16 && (form == AZ_NET_FORM_WINOGRAD || (form == AZ_NET_FORM_AUTO && s == 16)))                          \
+        if (s >= 16 && form == AZ_NET_FORM_WINOGRAD)                                                                     \
             return launch_team_wino<(s >= 16 ? s : 16)>(d_boards, d_leaf_kind, n, d_params, front_layers, policy_layers, \
                                                        value_layers, d_value, d_logp, st);                              \
         return launch<s>(d_boards, d_leaf_kind, n, d_params, front_layers, policy_layers, value_layers, d_value, d_logp, st);
+#ifdef AZ_NET_DEV_SHAPE // (development builds: one board size only)
+        AZ_NET_CASE(AZ_NET_DEV_SHAPE)
+#else
         AZ_NET_CASE(5) AZ_NET_CASE(6) AZ_NET_CASE(7) AZ_NET_CASE(8) AZ_NET_CASE(9) AZ_NET_CASE(10) AZ_NET_CASE(11)
         AZ_NET_CASE(12) AZ_NET_CASE(13) AZ_NET_CASE(14) AZ_NET_CASE(15) AZ_NET_CASE(16) AZ_NET_CASE(17)
         AZ_NET_CASE(18) AZ_NET_CASE(19) AZ_NET_CASE(20)
+#endif
 #undef AZ_NET_CASE
     default: return AZ_ERR_ARG;
     }

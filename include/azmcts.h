@@ -318,13 +318,14 @@ int az_aug_unique_average(int shape, int n_unique, const int *d_members, const i
  * 16 conv channels (config.py:12-15), layer counts as given. */
 int az_net_param_floats(int front_layers, int policy_layers, int value_layers);
 /* Which kernel az_net_eval runs (no counterpart in the reference; for tuning and for
- * tests that compare the forms): AUTO = by board size (one wavefront per position up to
- * 15x15, its 3x3 layers in the Winograd F(2x2,3x3) form from 12x12 on; a team of
- * wavefronts per position above 15x15, Winograd form at 16x16); DIRECT / WINOGRAD = that
- * form of the 3x3 layers for every size (one wavefront per position up to 15x15, a team
- * above; DIRECT above 15x15 is the same as TEAM); TEAM = the direct-form team kernel for
- * every size.  Process-wide; initial value from the environment (AZ_NET_FORM). */
-enum { AZ_NET_FORM_AUTO = 0, AZ_NET_FORM_DIRECT = 1, AZ_NET_FORM_WINOGRAD = 2, AZ_NET_FORM_TEAM = 3 };
+ * tests that compare the forms): AUTO = by board size (one wavefront per position and two
+ * per SIMD up to 15x15, the 3x3 layers in the Winograd F(2x2,3x3) form from 12x12 on; the
+ * Winograd kernel with one wavefront per SIMD above 15x15); DIRECT / WINOGRAD = that form
+ * of the 3x3 layers for every size (one wavefront per position up to 15x15, a team of
+ * four above; DIRECT above 15x15 is the same as TEAM); TEAM = the direct-form team kernel
+ * for every size; WIDE = the one-wavefront-per-SIMD Winograd kernel from 12x12 on (AUTO's
+ * choice below that).  Process-wide; initial value from the environment (AZ_NET_FORM). */
+enum { AZ_NET_FORM_AUTO = 0, AZ_NET_FORM_DIRECT = 1, AZ_NET_FORM_WINOGRAD = 2, AZ_NET_FORM_TEAM = 3, AZ_NET_FORM_WIDE = 4 };
 int az_net_set_form(int form);
 int az_net_eval(int shape, int n, const float *d_boards, const int *d_leaf_kind, const float *d_params,
                 int front_layers, int policy_layers, int value_layers, float *d_value, float *d_logp, void *stream);

@@ -34,7 +34,7 @@ def _boards(n, shape, seed):
     return b.reshape(n, 2, shape, shape)
 
 
-FORMS = {"auto": 0, "direct": 1, "winograd": 2, "team": 3}  # AZ_NET_FORM_* of include/azmcts.h
+FORMS = {"auto": 0, "direct": 1, "winograd": 2, "team": 3, "wide": 4}  # AZ_NET_FORM_* of include/azmcts.h
 
 
 @pytest.fixture
@@ -51,7 +51,7 @@ def net_form():
     lib.az_net_set_form(FORMS["auto"])
 
 
-@pytest.mark.parametrize("form", ["auto", "direct", "winograd", "team"])
+@pytest.mark.parametrize("form", ["auto", "direct", "winograd", "team", "wide"])
 @pytest.mark.parametrize("shape,front,pol,val,n", [(15, 4, 2, 2, 300), (13, 4, 2, 2, 50), (20, 3, 1, 2, 40),
                                                      (7, 1, 0, 0, 9), (5, 2, 3, 1, 1100), (14, 2, 0, 1, 70),
                                                      (12, 1, 1, 0, 33), (10, 3, 1, 1, 20), (6, 2, 1, 1, 5),
@@ -60,7 +60,8 @@ def net_form():
                                                      (20, 4, 2, 2, 600)])
 def test_fused_net_matches_torch_float64(shape, front, pol, val, n, form, net_form):
     """Every kernel form (one wavefront per position with direct or Winograd 3x3 layers, team of
-    wavefronts) against PyTorch float64, over every branch layout (no policy / value branch, trunk of one)."""
+    wavefronts, one wavefront per SIMD) against PyTorch float64, over every branch layout (no policy /
+    value branch, trunk of one)."""
     import torch
     from alphazero_amd.evaluator import FusedNetEvaluator
 

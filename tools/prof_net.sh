@@ -18,3 +18,4 @@ timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BU
 echo mfma done
 timeout -s KILL 120 rocprofv3 --pmc SQ_IFETCH SQ_WAIT_IFETCH SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM -d "$out/pmc_if" -o p --output-format csv -- $B > "$out/pmc_if.log" 2>&1 || echo "ifetch pass failed"
 echo ifetch done
+python3 tools/summarize_prof.py "$tag" "$out/stats" "$out/pmc_sq" "$out/pmc_sq2" "$out/pmc_mfma" "$out/pmc_if"

@@ -87,7 +87,10 @@ struct AzShapeOps {
     int shape;
     int sp;              // padded actions per node record of this shape
     int (*simulate_fused)(const AzParams &, const AzFusedArgs &, void *stream);
-    int (*select)(const AzParams &, float *d_boards, int *d_leaf_kind, void *stream);
+    // d_expand_mask / d_clear_mask (both may be null): bit t of the first is set when tree t's leaf is to be
+    // expanded; the second, the mask of the step before, is zeroed for the step after
+    int (*select)(const AzParams &, float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask, unsigned *d_clear_mask,
+                  void *stream);
     int (*expand_backup)(const AzParams &, const float *d_value, const float *d_prior,
                          int prior_is_log, void *stream);
     int (*make_move)(const AzParams &, const int *d_actions, void *stream);
@@ -99,5 +102,16 @@ struct AzShapeOps {
     int (*dirichlet)(double *d_table, int rows, double alpha, unsigned long long seed, void *stream);
     int (*restart)(const AzParams &, const int *d_openings, int n_plies, int *d_count, void *stream);
 };
+
+// Words of the expand masks are AZ_MASK_STRIDE words apart: the trees' atomic ORs then spread over four times
+// as many cache lines (8192 atomics on eight lines cost k_select 5 us), while a reader still fetches only 4 KB.
+#define AZ_MASK_STRIDE 4
+
+// az_net_eval (az_net.hip) with the bit mask k_select fills (one bit per position, word w at index
+// w * AZ_MASK_STRIDE, set = evaluate it; null: the codes are scanned as az_net_eval does).  Internal to the
+// library: az_simulate_net's steps.
+int az_net_eval_masked(int shape, int n, const float *d_boards, const int *d_leaf_kind, const unsigned *d_expand_mask,
+                       const float *d_params, int front_layers, int policy_layers, int value_layers, float *d_value,
+                       float *d_logp, void *stream);
 
 #endif

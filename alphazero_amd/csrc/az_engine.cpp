@@ -481,7 +481,7 @@ int az_select(az_engine *e, float *d_boards, int *d_leaf_kind, void *stream)
 {
     if (!e || !d_boards || !d_leaf_kind) return fail(AZ_ERR_ARG, "null argument");
     DeviceGuard g(e->device);
-    if (e->ops->select(e->P, d_boards, d_leaf_kind, stream)) return fail(AZ_ERR_HIP, "select launch failed");
+    if (e->ops->select(e->P, d_boards, d_leaf_kind, nullptr, nullptr, stream)) return fail(AZ_ERR_HIP, "select launch failed");
     return AZ_OK;
 }
 
@@ -496,9 +496,10 @@ int az_expand_backup(az_engine *e, const float *d_value, const float *d_prior, i
 
 // Staging of one search step between az_select, az_net_eval and az_expand_backup
 // for n trees of `size` actions: leaf boards float [n][2][size], log-priors float
-// [n][size], values float [n], leaf codes int [n]; every section 256-byte aligned.
+// [n][size], values float [n], leaf codes int [n], two bit masks of the trees whose
+// leaf is to be expanded (steps alternate between them); every section 256-byte aligned.
 struct StageLayout {
-    size_t boards, logp, value, kinds, bytes;
+    size_t boards, logp, value, kinds, mask[2], mask_bytes, bytes;
 };
 static StageLayout stage_layout(int n, int size)
 {
@@ -508,7 +509,10 @@ static StageLayout stage_layout(int n, int size)
     L.logp = up((size_t)n * 2 * size * sizeof(float));
     L.value = L.logp + up((size_t)n * size * sizeof(float));
     L.kinds = L.value + up((size_t)n * sizeof(float));
-    L.bytes = L.kinds + up((size_t)n * sizeof(int));
+    L.mask_bytes = up((size_t)((n + 31) / 32) * AZ_MASK_STRIDE * sizeof(unsigned));
+    L.mask[0] = L.kinds + up((size_t)n * sizeof(int));
+    L.mask[1] = L.mask[0] + L.mask_bytes;
+    L.bytes = L.mask[1] + L.mask_bytes;
     return L;
 }
 
@@ -522,6 +526,9 @@ static int simulate_net_steps(az_engine *e, int n, const float *d_params, int fr
     float *logp = reinterpret_cast<float *>(stage + L.logp);
     float *value = reinterpret_cast<float *>(stage + L.value);
     int *kinds = reinterpret_cast<int *>(stage + L.kinds);
+    unsigned *mask[2] = {reinterpret_cast<unsigned *>(stage + L.mask[0]), reinterpret_cast<unsigned *>(stage + L.mask[1])};
+    HIP_TRY(hipMemsetAsync(stage + L.mask[0], 0, 2 * L.mask_bytes, (hipStream_t)stream));
+    int step = 0;
     // thread fan-out of cmcts.cpp:98-119: th_num workers of `per` searches, one after another
     int th_num = 1, per = n;
     if (e->threads > 1) {
@@ -535,8 +542,10 @@ static int simulate_net_steps(az_engine *e, int n, const float *d_params, int fr
         HIP_TRY(hipMemset2DAsync((char *)e->P.trees + offsetof(AzTree, noise_row), sizeof(AzTree), 0, sizeof(int),
                                  e->n_trees, (hipStream_t)stream));
         for (int i = 0; i < per; i++) {
-            if (e->ops->select(e->P, boards, kinds, stream)) return fail(AZ_ERR_HIP, "select launch failed");
-            if (int rc = az_net_eval(e->shape, e->n_trees, boards, kinds, d_params, front, pol, val, value, logp, stream))
+            unsigned *cur = mask[step & 1], *other = mask[(step + 1) & 1];
+            step++;
+            if (e->ops->select(e->P, boards, kinds, cur, other, stream)) return fail(AZ_ERR_HIP, "select launch failed");
+            if (int rc = az_net_eval_masked(e->shape, e->n_trees, boards, kinds, cur, d_params, front, pol, val, value, logp, stream))
                 return fail(rc, "network evaluation launch failed");
             if (e->ops->expand_backup(e->P, value, logp, 1, stream)) return fail(AZ_ERR_HIP, "expand_backup launch failed");
         }

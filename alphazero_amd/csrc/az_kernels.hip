@@ -1082,12 +1082,17 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
 // Cmcts::search down to the leaf (mcts/src/cmcts.cpp:189-268) for an external
 // evaluator, one wavefront per tree.  Virtual loss is stored
 // (node.cpp:115-118) because the backup runs in a later launch.
-__global__ __launch_bounds__(64) void k_select(AzParams P, float *d_boards, int *d_leaf_kind)
+// d_expand_mask (may be null): one bit per tree, set here when the leaf is to be expanded, for an evaluator
+// that wants the list of those trees without scanning the codes; d_clear_mask: the mask of the step
+// before, which nobody reads any more, zeroed here for the step after (the caller alternates two masks).
+__global__ __launch_bounds__(64) void k_select(AzParams P, float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask,
+                                               unsigned *d_clear_mask)
 {
     constexpr int E = EPL;
     const int tree = blockIdx.x;
     const int lane = threadIdx.x;
     AzTree *T = &P.trees[tree];
+    if (d_clear_mask != nullptr && lane == 0 && (tree & 31) == 0) d_clear_mask[(tree >> 5) * AZ_MASK_STRIDE] = 0u;
     if (uni(T->active) == 0 || uni(T->err) != 0) {
         if (lane == 0) { T->leaf_kind = AZ_LEAF_NONE; d_leaf_kind[tree] = AZ_LEAF_NONE; }
         return;
@@ -1143,6 +1148,7 @@ __global__ __launch_bounds__(64) void k_select(AzParams P, float *d_boards, int 
         T->stats[3] += n_sel;
         if (err) T->err = err;
         d_leaf_kind[tree] = kind;
+        if (d_expand_mask != nullptr && kind == AZ_LEAF_EXPAND) atomicOr(&d_expand_mask[(tree >> 5) * AZ_MASK_STRIDE], 1u << (tree & 31));
     }
 }
 
@@ -1643,9 +1649,10 @@ int l_simulate_fused(const AzParams &P, const AzFusedArgs &A, void *stream)
         hipLaunchKernelGGL((k_simulate_fused<1, AZ_EVAL_HASH, 1>), grid, dim3(64), 0, st, P, A);
     return launch_status();
 }
-int l_select(const AzParams &P, float *d_boards, int *d_leaf_kind, void *stream)
+int l_select(const AzParams &P, float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask, unsigned *d_clear_mask, void *stream)
 {
-    hipLaunchKernelGGL(k_select, dim3(P.n_trees), dim3(64), 0, (hipStream_t)stream, P, d_boards, d_leaf_kind);
+    hipLaunchKernelGGL(k_select, dim3(P.n_trees), dim3(64), 0, (hipStream_t)stream, P, d_boards, d_leaf_kind, d_expand_mask,
+                       d_clear_mask);
     return launch_status();
 }
 int l_expand_backup(const AzParams &P, const float *d_value, const float *d_prior, int is_log, void *stream)

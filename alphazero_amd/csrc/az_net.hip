@@ -27,6 +27,7 @@
 #include <atomic>
 
 #include "../../include/azmcts.h"
+#include "az_common.h"
 
 namespace {
 
@@ -153,11 +154,73 @@ template <int NTHR> __device__ __forceinline__ int list_positions(const int *lea
     const int first = (int)((long long)blockIdx.x * total / (int)gridDim.x);
     const int last = (int)((long long)(blockIdx.x + 1) * total / (int)gridDim.x); // (exclusive)
     if (c > 0 && before < last && before + c > first) {
-        for (int i = lo; i < hi && before < last; i++)
+        int i = lo;
+        if (aligned) {
+            // 32 codes per round, their loads issued together: a walk code by code would pay the full memory
+            // latency for every code (the loop's exit depends on the codes before)
+            for (; i + 31 < hi && before < last; i += 32) {
+                int4 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = *reinterpret_cast<const int4 *>(leaf_kind + i + 4 * q);
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const bool ex = e[r] == AZ_LEAF_EXPAND;
+                        if (ex && before >= first && before < last) todo[before - first] = i + 4 * q + r;
+                        before += ex ? 1 : 0;
+                    }
+                }
+            }
+        }
+        for (; i < hi && before < last; i++)
             if (leaf_kind[i] == AZ_LEAF_EXPAND) {
                 if (before >= first) todo[before - first] = i;
                 before++;
             }
+    }
+    __syncthreads();
+    return last - first;
+}
+
+// The same run, found from a bit mask (bit i set = position i needs an evaluation; bits past n are clear; word w
+// at index w * AZ_MASK_STRIDE)
+// instead of the codes: one wavefront reads the whole mask in one or a few loads per lane, so the list
+// costs a workgroup about a microsecond where scanning the codes costs ten (2048 workgroups reading 32 KB
+// of codes each is 64 MB of L2 traffic per launch).  For a single wavefront (NTHR = 64).
+__device__ __forceinline__ int list_positions_mask(const unsigned *mask, int n, int *todo, int lane)
+{
+    const int words = (n + 31) >> 5;
+    const int per = (words + 63) >> 6; // words per lane, consecutive
+    const int lo = lane * per, hi = lo + per < words ? lo + per : words;
+    int c = 0;
+    for (int w = lo; w < hi; w++) c += __popc(mask[w * AZ_MASK_STRIDE]);
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    int before = incl - c;
+    const int total = __shfl(incl, 63);
+    const int first = (int)((long long)blockIdx.x * total / (int)gridDim.x);
+    const int last = (int)((long long)(blockIdx.x + 1) * total / (int)gridDim.x); // (exclusive)
+    if (c > 0 && before < last && before + c > first) {
+        for (int w = lo; w < hi && before < last; w++) {
+            unsigned m = mask[w * AZ_MASK_STRIDE];
+            const int pc = __popc(m);
+            if (before + pc <= first) { // the whole word lies before the run
+                before += pc;
+                continue;
+            }
+            while (m != 0u && before < last) {
+                const int b = __ffs(m) - 1;
+                m &= m - 1u;
+                if (before >= first) todo[before - first] = w * 32 + b;
+                before++;
+            }
+        }
     }
     __syncthreads();
     return last - first;
@@ -1032,8 +1095,8 @@ template <int S> __device__ __forceinline__ void policy_taps_rows(float *buf, co
 
 template <int S, bool WINO>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_solo(
-    const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val, float *value_out,
-    float *logp_out)
+    const float *boards, const int *leaf_kind, const unsigned *expand_mask, int n, const float *prm, int front, int pol, int val,
+    float *value_out, float *logp_out)
 {
     using G = Geo<S>;
     constexpr int NT = G::NT;
@@ -1072,7 +1135,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const float wv = p_value[co], v_bias = p_value[CH];
 
     int n_mine;
-    if (leaf_kind != nullptr) {
+    const bool listed = expand_mask != nullptr || leaf_kind != nullptr; // positions come from todo[]
+    if (expand_mask != nullptr) {
+        n_mine = list_positions_mask(expand_mask, n, todo, lane);
+    } else if (leaf_kind != nullptr) {
         n_mine = list_positions<64>(leaf_kind, n, todo, nullptr, lane);
     } else {
         n_mine = n > (int)blockIdx.x ? (n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
@@ -1106,7 +1172,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             in1[i] = p < G::SIZE ? bp[G::SIZE + p] : 0.f;
         }
     };
-    if (n_mine > 0) request_board(leaf_kind != nullptr ? todo[0] : (int)blockIdx.x);
+    if (n_mine > 0) request_board(listed ? todo[0] : (int)blockIdx.x);
     // the weights of the first 16-channel layer: loaded here once, later rolled in by the last layer
     LayerRegs<WINO ? 1 : 36> wq;
     float u[WINO ? 64 : 1], ush = 0.f;
@@ -1124,7 +1190,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (nl > 0) load_layer<36>(layer_params(0), lane, wq);
     }
     for (int it = 0; it < n_mine; it++) {
-        const int pos = leaf_kind != nullptr ? todo[it] : (int)blockIdx.x + it * (int)gridDim.x;
+        const int pos = listed ? todo[it] : (int)blockIdx.x + it * (int)gridDim.x;
 #ifdef AZ_NET_STAMPS
         st_t = __builtin_readcyclecounter();
 #endif
@@ -1173,6 +1239,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     __syncthreads();
                 }
                 const float sh = ush;
+                ush = nextp[64 * 64 + co]; // (requested a layer ahead: its latency runs under this layer)
                 NST(4);
                 float lsum = 0.f;
                 if (last_value) wino_layer<S, 4, true, false, false, true>(buf, u, nextp, sh, lane, fc, fz, lsum);
@@ -1180,7 +1247,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 else if (last_trunk) wino_layer<S, 4, true, true, false, true>(buf, u, nextp, sh, lane, fc, fz, lsum);
                 else wino_layer<S, 4, true, true, false, false>(buf, u, nextp, sh, lane, fc, fz, lsum);
                 if (last_value || (last_trunk && val == 0)) vsum = lsum;
-                ush = nextp[64 * 64 + co];
                 __syncthreads();
                 NST(1);
             } else {
@@ -1225,7 +1291,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int o = 1; o < 64; o <<= 1) vpart += __shfl_xor(vpart, o);
         }
         if (lane == 0) value_out[pos] = tanhf(vpart / (float)G::SIZE + v_bias);
-        if (it + 1 < n_mine) request_board(leaf_kind != nullptr ? todo[it + 1] : (int)blockIdx.x + (it + 1) * (int)gridDim.x);
+        if (it + 1 < n_mine) request_board(listed ? todo[it + 1] : (int)blockIdx.x + (it + 1) * (int)gridDim.x);
         // ---- policy head: per-tap partial planes on the matrix cores, written over the input
         if constexpr (WINO) policy_taps_rows<S>(buf, wp.b, lane);
         else solo_mma<S, 4, false>(buf, wp, prm, m, off0, lane, 0.f, acc, cacc);
@@ -1822,8 +1888,8 @@ template <int S> __device__ __forceinline__ void policy_taps_wide(float *buf, co
 
 template <int S>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_net_wide(
-    const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val, float *value_out,
-    float *logp_out)
+    const float *boards, const int *leaf_kind, const unsigned *expand_mask, int n, const float *prm, int front, int pol, int val,
+    float *value_out, float *logp_out)
 {
     using G = Geo<S>;
     using W = WideGeo<S>;
@@ -1850,7 +1916,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const float wv = p_value[co], v_bias = p_value[CH];
 
     int n_mine;
-    if (leaf_kind != nullptr) {
+    const bool listed = expand_mask != nullptr || leaf_kind != nullptr; // positions come from todo[]
+    if (expand_mask != nullptr) {
+        n_mine = list_positions_mask(expand_mask, n, todo, lane);
+    } else if (leaf_kind != nullptr) {
         n_mine = list_positions<64>(leaf_kind, n, todo, nullptr, lane);
     } else {
         n_mine = n > (int)blockIdx.x ? (n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
@@ -1871,7 +1940,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             in1[i] = p < G::SIZE ? bp[G::SIZE + p] : 0.f;
         }
     };
-    if (n_mine > 0) request_board(leaf_kind != nullptr ? todo[0] : (int)blockIdx.x);
+    if (n_mine > 0) request_board(listed ? todo[0] : (int)blockIdx.x);
     float u[64], ush = 0.f; // the weights of the first 16-channel layer: loaded here once, later rolled in by the last layer
     float u0[16];           // the input layer
 #pragma unroll
@@ -1882,7 +1951,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         ush = layer_params(0)[64 * 64 + co];
     }
     for (int it = 0; it < n_mine; it++) {
-        const int pos = leaf_kind != nullptr ? todo[it] : (int)blockIdx.x + it * (int)gridDim.x;
+        const int pos = listed ? todo[it] : (int)blockIdx.x + it * (int)gridDim.x;
 #pragma unroll
         for (int i = 0; i < PPL; i++) { // the two input planes (requested while the previous position was in its heads)
             const int p = lane + 64 * i;
@@ -1910,13 +1979,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 __syncthreads();
             }
             const float sh = ush;
+            ush = nextp[64 * 64 + co]; // (requested a layer ahead: its latency runs under this layer)
             lsum = 0.f;
             if (last_value) wide_layer<S, 4, true, false, false, true>(buf, u, nextp, sh, lane, fc, lsum);
             else if (last_trunk && val > 0) wide_layer<S, 4, true, true, true, false>(buf, u, nextp, sh, lane, fc, lsum);
             else if (last_trunk) wide_layer<S, 4, true, true, false, true>(buf, u, nextp, sh, lane, fc, lsum);
             else wide_layer<S, 4, true, true, false, false>(buf, u, nextp, sh, lane, fc, lsum);
             if (last_value || (last_trunk && val == 0)) vsum = lsum;
-            ush = nextp[64 * 64 + co];
             __syncthreads();
         }
         // policy head input: the policy branch's output, or the trunk output when there is no such branch
@@ -1927,7 +1996,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // ---- value head: board average of the 1x1 convolution + bias, tanh
         const float vpart = wave_reduce<false>(wv * vsum);
         if (lane == 0) value_out[pos] = tanhf(vpart / (float)G::SIZE + v_bias);
-        if (it + 1 < n_mine) request_board(leaf_kind != nullptr ? todo[it + 1] : (int)blockIdx.x + (it + 1) * (int)gridDim.x);
+        if (it + 1 < n_mine) request_board(listed ? todo[it + 1] : (int)blockIdx.x + (it + 1) * (int)gridDim.x);
         // ---- policy head: per-tap partial planes on the matrix cores, written over the input
         policy_taps_wide<S>(buf, wpb, lane);
         __syncthreads();
@@ -1958,8 +2027,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 }
 
-template <int S> int launch_wide(const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val,
-                                 float *value_out, float *logp_out, hipStream_t st)
+template <int S> int launch_wide(const float *boards, const int *leaf_kind, const unsigned *expand_mask, int n, const float *prm,
+                                 int front, int pol, int val, float *value_out, float *logp_out, hipStream_t st)
 {
     using W = WideGeo<S>;
     int dev = 0, cus = 256;
@@ -1973,8 +2042,8 @@ template <int S> int launch_wide(const float *boards, const int *leaf_kind, int 
             return AZ_ERR_HIP;
         if (dev >= 0 && dev < 64) configured[dev] = lds_bytes;
     }
-    hipLaunchKernelGGL(k_net_wide<S>, dim3(grid), dim3(64), lds_bytes, st, boards, leaf_kind, n, prm, front, pol, val, value_out,
-                       logp_out);
+    hipLaunchKernelGGL(k_net_wide<S>, dim3(grid), dim3(64), lds_bytes, st, boards, leaf_kind, expand_mask, n, prm, front, pol, val,
+                       value_out, logp_out);
     return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
 }
 
@@ -1999,10 +2068,10 @@ template <int S> int launch_team_wino(const float *boards, const int *leaf_kind,
     return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
 }
 
-template <int S, bool WINO> int launch_solo(const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val,
-                                 float *value_out, float *logp_out, hipStream_t st)
+template <int S, bool WINO> int launch_solo(const float *boards, const int *leaf_kind, const unsigned *expand_mask, int n,
+                                            const float *prm, int front, int pol, int val, float *value_out, float *logp_out,
+                                            hipStream_t st)
 {
-    using G = Geo<S>;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     static const int wgs_override = getenv("AZ_NET_SOLO_WGS") != nullptr ? atoi(getenv("AZ_NET_SOLO_WGS")) : 0; // (experiments)
@@ -2016,8 +2085,8 @@ template <int S, bool WINO> int launch_solo(const float *boards, const int *leaf
             return AZ_ERR_HIP;
         if (dev >= 0 && dev < 64) configured[dev] = lds_bytes;
     }
-    hipLaunchKernelGGL((k_net_solo<S, WINO>), dim3(grid), dim3(64), lds_bytes, st, boards, leaf_kind, n, prm, front, pol, val, value_out,
-                       logp_out);
+    hipLaunchKernelGGL((k_net_solo<S, WINO>), dim3(grid), dim3(64), lds_bytes, st, boards, leaf_kind, expand_mask, n, prm, front, pol,
+                       val, value_out, logp_out);
     return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
 }
 
@@ -2069,6 +2138,17 @@ int az_net_param_floats(int front_layers, int policy_layers, int value_layers)
 int az_net_eval(int shape, int n, const float *d_boards, const int *d_leaf_kind, const float *d_params,
                 int front_layers, int policy_layers, int value_layers, float *d_value, float *d_logp, void *stream)
 {
+    return az_net_eval_masked(shape, n, d_boards, d_leaf_kind, nullptr, d_params, front_layers, policy_layers, value_layers, d_value,
+                              d_logp, stream);
+}
+
+} // extern "C"
+
+// d_expand_mask: see az_common.h.  The kernels that are nobody's default (the teams) go by the codes.
+int az_net_eval_masked(int shape, int n, const float *d_boards, const int *d_leaf_kind, const unsigned *d_expand_mask,
+                       const float *d_params, int front_layers, int policy_layers, int value_layers, float *d_value,
+                       float *d_logp, void *stream)
+{
     if (n < 0 || front_layers < 1 || policy_layers < 0 || value_layers < 0) return AZ_ERR_ARG;
     if (n == 0) return AZ_OK;
     if (!d_boards || !d_params || !d_value || !d_logp) return AZ_ERR_ARG;
@@ -2084,13 +2164,13 @@ int az_net_eval(int shape, int n, const float *d_boards, const int *d_leaf_kind,
 #define AZ_NET_CASE(s)                                                                                                   \
     case s:                                                                                                              \
         if (s >= 12 && (form == AZ_NET_FORM_WIDE || (form == AZ_NET_FORM_AUTO && s >= 16)))                              \
-            return launch_wide<(s >= 12 ? s : 12)>(d_boards, d_leaf_kind, n, d_params, front_layers, policy_layers,      \
-                                                   value_layers, d_value, d_logp, st);                                   \
+            return launch_wide<(s >= 12 ? s : 12)>(d_boards, d_leaf_kind, d_expand_mask, n, d_params, front_layers,      \
+                                                   policy_layers, value_layers, d_value, d_logp, st);                    \
         if (s <= 15 && !team && wino)                                                                                    \
-            return launch_solo<(s <= 15 ? s : 15), true>(d_boards, d_leaf_kind, n, d_params, front_layers,               \
+            return launch_solo<(s <= 15 ? s : 15), true>(d_boards, d_leaf_kind, d_expand_mask, n, d_params, front_layers, \
                                                          policy_layers, value_layers, d_value, d_logp, st);              \
         if (s <= 15 && !team)                                                                                            \
-            return launch_solo<(s <= 15 ? s : 15), false>(d_boards, d_leaf_kind, n, d_params, front_layers,              \
+            return launch_solo<(s <= 15 ? s : 15), false>(d_boards, d_leaf_kind, d_expand_mask, n, d_params, front_layers, \
                                                           policy_layers, value_layers, d_value, d_logp, st);             \
         if (s >= 16 && form == AZ_NET_FORM_WINOGRAD)                                                                     \
             return launch_team_wino<(s >= 16 ? s : 16)>(d_boards, d_leaf_kind, n, d_params, front_layers, policy_layers, \
@@ -2108,4 +2188,4 @@ int az_net_eval(int shape, int n, const float *d_boards, const int *d_leaf_kind,
     }
 }
 
-} // extern "C"
+

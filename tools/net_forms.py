@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--lib", default=None)
+    ap.add_argument("--kinds", action="store_true", help="pass leaf codes (all AZ_LEAF_EXPAND), as the search does")
+    ap.add_argument("--interleave", action="store_true", help="a small elementwise kernel between the launches")
     args = ap.parse_args()
     import torch
     from alphazero_amd import engine as E
@@ -34,16 +36,20 @@ def main():
         torch.manual_seed(0)
         ev = FusedNetEvaluator(PolicyValueNet(s).eval(), s)
         b = (torch.rand(args.n, 2, s, s, device="cuda") < 0.2).float()
+        kinds = torch.ones(args.n, dtype=torch.int32, device="cuda") if args.kinds else None
+        scratch = torch.zeros(1 << 20, device="cuda")
         flops = 2.0 * s * s * (9 * 2 * 16 + 7 * 9 * 16 * 16 + 9 * 16 + 16)
         for f in [int(x) for x in args.forms.split(",")]:
             assert ev.L.az_net_set_form(f) == 0
             for _ in range(3):
-                ev(b)
+                ev(b, kinds)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(args.reps):
-                ev(b)
+                ev(b, kinds)
+                if args.interleave:
+                    scratch.add_(1.0)
             e1.record()
             e1.synchronize()
             ms = e0.elapsed_time(e1) / args.reps

@@ -585,7 +585,7 @@ int az_simulate_net_noalloc(az_engine *e, int n, const float *d_params, int fron
                     "az_simulate_net_noalloc: %d trees of %dx%d need %zu bytes of step staging, the fixed buffer "
                     "holds %u (about %zu trees of this shape); use az_simulate_net",
                     e->n_trees, e->shape, e->shape, L.bytes, AZ_NOALLOC_SCRATCH_BYTES,
-                    (size_t)(AZ_NOALLOC_SCRATCH_BYTES - 1024) / per_tree);
+                    (size_t)(AZ_NOALLOC_SCRATCH_BYTES - 4096) / (per_tree + 1));
     }
     DeviceGuard g(e->device);
     char *ptr = g_scratch_ptr[e->device]; // resolved by az_create on this device

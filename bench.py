@@ -362,7 +362,7 @@ def secondary_net(torch, E, dev_index, trees=8192, shape=SHAPE, sims=SIMS, label
         return {"workload": label, "error": f"{type(e).__name__}: {e}"}
 
 
-def secondary_games(torch, dev_index, mode, games=4096, shape=SHAPE, sims=100, tau=10):
+def secondary_games(torch, dev_index, mode, games=4096, shape=SHAPE, sims=100, tau=10, slots=0):
     """Whole games end to end on one GPU through the batched drivers: `self_play_game`
     (src/self_play.py:134-202; records assembled on the host, as the sample gather takes
     them) or the arena's `eval_game` with two networks and the noise on (src/eval.py:187-209,
@@ -379,17 +379,23 @@ def secondary_games(torch, dev_index, mode, games=4096, shape=SHAPE, sims=100, t
             nets.append(FusedNetEvaluator(PolicyValueNet(shape).eval(), shape, dev, name=f"seed{seed}"))
         second = nets[0] if mode == "selfplay" else nets[1]
         nodes = sims * 3 + 64
-        b0 = sp.TreeBatch(games, shape, nets[0], cpuct=CPUCT, eps=0.25, nodes_per_tree=nodes, device=dev_index, noise_seed=0)
-        b1 = sp.TreeBatch(games, shape, second, cpuct=CPUCT, eps=0.25, nodes_per_tree=nodes, device=dev_index, noise_seed=1000)
+        width = slots if slots > 0 else games  # trees per batch
+        b0 = sp.TreeBatch(width, shape, nets[0], cpuct=CPUCT, eps=0.25, nodes_per_tree=nodes, device=dev_index, noise_seed=0)
+        b1 = sp.TreeBatch(width, shape, second, cpuct=CPUCT, eps=0.25, nodes_per_tree=nodes, device=dev_index, noise_seed=1000)
         try:
-            first = np.arange(games, dtype=np.int32) % (shape * shape)  # distinct first stones
-            b0.make_move(first)
-            b1.make_move(first)
+            if slots == 0:
+                first = np.arange(games, dtype=np.int32) % (shape * shape)  # distinct first stones
+                b0.make_move(first)
+                b1.make_move(first)
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             rec = {"workload": f"{mode}: {games} games of {shape}x{shape} to the end, {sims} sims/move, reference net "
-                               f"(seed 0{'' if mode == 'selfplay' else ' vs seed 1'}), eps=0.25, cpuct=4"}
-            if mode == "selfplay":
+                               f"(seed 0{'' if mode == 'selfplay' else ' vs seed 1'}), eps=0.25, cpuct=4"
+                               + (f", {slots} tree slots per batch, a finished game's slot goes to the next game" if slots else "")}
+            if mode == "selfplay" and slots > 0:
+                data = sp.self_play_stream(b0, b1, sims, tau, games, rng=np.random.default_rng(0))
+                n_samples = sum(len(g) for g in data)
+            elif mode == "selfplay":
                 data = sp.self_play_games_device(b0, b1, sims, tau, rng=np.random.default_rng(0))
                 n_samples = sum(len(g) for g in data)
             else:
@@ -464,7 +470,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--only", default=None,
                     help="run one secondary workload alone and print its record (for profiling): "
-                         + ", ".join(list(HASH_WORKLOADS) + ["config3", "config4_share", "config3_games", "config5_share"]))
+                         + ", ".join(list(HASH_WORKLOADS) + ["config3", "config4_share", "config3_games", "config3_stream", "config5_share"]))
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -508,6 +514,7 @@ def main():
         rec = (secondary_net(torch, E, dev_index) if args.only == "config3"
                else config4_share(torch, E, dev_index) if args.only == "config4_share"
                else secondary_games(torch, dev_index, "selfplay") if args.only == "config3_games"
+               else secondary_games(torch, dev_index, "selfplay", games=16384, slots=8192) if args.only == "config3_stream"
                else secondary_games(torch, dev_index, "arena") if args.only == "config5_share"
                else secondary_hash(torch, E, dev_index, args.only, *HASH_WORKLOADS[args.only], traffic))
         print(json.dumps(rec), flush=True)
@@ -572,6 +579,7 @@ def main():
                 "config3": secondary_net(torch, E, dev_index),
                 "config4_share": config4_share(torch, E, dev_index),
                 "config3_games": secondary_games(torch, dev_index, "selfplay"),
+                "config3_stream": secondary_games(torch, dev_index, "selfplay", games=16384, slots=8192),
                 "config5_share": secondary_games(torch, dev_index, "arena"),
             }
         print(json.dumps(out), flush=True)

@@ -89,6 +89,58 @@ def test_simulate_net_equals_the_three_step_path(S, threads):
     b.close()
 
 
+@pytest.mark.parametrize("B,S,plies", [(77, 5, 24), (130, 7, 3), (33, 16, 3)])
+def test_simulate_net_position_mask_with_idle_and_terminal_leaves(B, S, plies):
+    """az_simulate_net tells its evaluator which positions to evaluate through the bit mask az_select
+    fills (the three-step path scans the leaf codes): tree counts that are no multiple of 32, idle trees
+    and, on small boards, searches that end on finished games; every statistic stays bit-identical."""
+    import torch
+    from alphazero_amd import engine as E
+
+    sims, size = 40, S * S  # (5x5: the board fills up, searches end on finished games and the games themselves end)
+    _, ev = _fused(S, seed=5)
+    active = (np.arange(B) % 5 != 2).astype(np.uint8)
+    engs = []
+    for _ in range(2):
+        e = E.Engine(B, S, nodes_per_tree=sims * plies + 64, cpuct=4.0)
+        e.set_alpha_default()
+        e.set_eps(0.25)
+        e.set_noise_table(np.random.default_rng(9).dirichlet(np.full(size, e.get_alpha()), size=sims + 2))
+        e.make_move(np.array([O.opening(size, 3 * g + 2)[0] for g in range(B)], np.int32))
+        e.set_active(active)
+        engs.append(e)
+    a, b = engs
+    stream = torch.cuda.current_stream().cuda_stream
+    terminals = 0
+    for ply in range(plies):
+        a.simulate_net(sims, ev.params.data_ptr(), ev.fused_layers, stream)
+        a.sync_check(stream)
+        _stepped(b, torch, ev, sims)
+        ca, ra = a.get_counts()
+        cb, rb = b.get_counts()
+        assert np.array_equal(ra, rb) and np.array_equal(ca, cb), ply
+        assert a.get_stats() == b.get_stats()
+        assert not ca[active == 0].any()  # idle trees were not searched
+        for t in range(0, B, 7):
+            na, nb = a.get_node(t, []), b.get_node(t, [])
+            if na is None or nb is None:  # a tree that was never searched has no root node
+                assert na is None and nb is None and active[t] == 0
+                continue
+            assert np.array_equal(na[2], nb[2]) and np.array_equal(na[3], nb[3]), (ply, t)
+        terminals = a.get_stats()["terminals"]
+        act = np.where(active == 1, ca.argmax(axis=1), -1).astype(np.int32)  # a negative action leaves the tree alone
+        for eng in (a, b):
+            eng.make_move(act)
+        # games that are over leave the search
+        active = (active.astype(bool) & (a.get_states()[2] == -1.0)).astype(np.uint8)
+        for eng in (a, b):
+            eng.set_active(active)
+    if S == 5:
+        assert terminals > 0 and not active.any()  # searches reached finished games; every game is over
+    a.close()
+    b.close()
+
+
 def test_simulate_net_matches_oracle():
     """The engine-driven network search against the CPU oracle, whose predictor returns
     what the fused kernel computes for the position it is asked about (batch of one):

@@ -615,10 +615,12 @@ __device__ __forceinline__ Pick select_pick(const NodeRegs<E> &nd, bool fresh, d
 
 // sqrt(nodeN + 1e-8) (node.cpp:106,108): a table of the same fp64 operation for
 // the first SQ_TAB values (nodeN is an integer), the operation itself beyond
-constexpr int SQ_TAB = 2048;
-__device__ __forceinline__ double sqrt_from_table(int node_n, const double *tab) // tab: an LDS table, never null
+constexpr int SQ_TAB = 2048;     // entries of the table when one wavefront has a SIMD to itself
+constexpr int SQ_TAB_LEAN = 512; // ... when the launch wants three wavefronts per SIMD (LDS bounds the residency)
+template <int TAB = SQ_TAB>
+__device__ __forceinline__ double sqrt_from_table(int node_n, const double *tab) // tab: an LDS table of TAB entries, never null
 {
-    if (AZ_LIKELY(node_n < SQ_TAB)) return tab[node_n];
+    if (AZ_LIKELY(node_n < TAB)) return tab[node_n];
     return __dsqrt_rn((double)node_n + 1e-8);
 }
 __device__ __forceinline__ double sqrt_node_n(int node_n, const double *tab)
@@ -755,18 +757,24 @@ __device__ __forceinline__ int pop_free(const AzParams &P, size_t tbase, int &fr
 // separately rounded fp64 operations, kept as such: w1 = W - 1.0 at select,
 // W = w1 + (value + 1.0) at backup; only the final W is stored because no other
 // search of this tree can observe the intermediate.
-// EARLY_LOAD: request the likely next root pick's child record one search ahead
-// (-DAZ_NO_EARLY_LOAD builds the kernel without it, for A/B timing)
-#ifdef AZ_NO_EARLY_LOAD
-constexpr bool EARLY_LOAD = false;
-#else
-constexpr bool EARLY_LOAD = true;
-#endif
+// LEAN = false: the form for launches of about one wavefront per SIMD.  The child record of the likely next
+//   root pick is requested one search ahead into registers of its own (EARLY_LOAD) and the sqrt table has
+//   2048 entries: 166-182 registers and 19 KB of LDS, i.e. two wavefronts per SIMD at most.
+// LEAN = true: the form for launches of many trees.  No early load (24 registers less) and a table of 512
+//   entries (sqrt computed beyond it): three wavefronts per SIMD.  Measured on MI355X at 15x15, uniform
+//   evaluator: 1024 trees 9 % slower, 2048 trees 3 % faster, 8192 trees 5 % faster; hash evaluator (whose
+//   next pick is harder to predict): 1024 trees 4 % faster, 8192 trees 21 % faster.  (A form forced down to
+//   128 registers for four wavefronts per SIMD spills and is no faster than two.)
 // EVAL / MIX: see evaluate() and mix_prior(); the launcher picks the instance,
 // so the evaluator and noise tests leave the search loop.
-template <int WPT, int EVAL, int MIX>
-__global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFusedArgs A)
+#ifndef AZ_FUSED_ATTR
+#define AZ_FUSED_ATTR
+#endif
+template <int WPT, int EVAL, int MIX, bool LEAN = false>
+__global__ __launch_bounds__(64 * WPT) AZ_FUSED_ATTR void k_simulate_fused(AzParams P, AzFusedArgs A)
 {
+    constexpr bool EARLY_LOAD = !LEAN;
+    constexpr int TAB = LEAN ? SQ_TAB_LEAN : SQ_TAB;
     constexpr int T = 64 * WPT;
     static_assert(SP % T == 0, "group does not tile the padded action range");
     constexpr int E = SP / T;
@@ -783,9 +791,9 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
     __shared__ double s_w1[PATH_SPILL];
     PathRegs path = {0, 0, 0, 0};
     __shared__ Slot s_slots[2 * WPT];
-    __shared__ double s_sqrt[SQ_TAB];
+    __shared__ double s_sqrt[TAB];
     int phase = 0;
-    for (int i = tid; i < SQ_TAB; i += T) s_sqrt[i] = __dsqrt_rn((double)i + 1e-8);
+    for (int i = tid; i < TAB; i += T) s_sqrt[i] = __dsqrt_rn((double)i + 1e-8);
     __syncthreads();
 
     WState root_state;
@@ -827,7 +835,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
     int pf_last = 0, pf_hit = 0, pf_total = 0;
 #endif
 
-    double sq_root = sqrt_from_table(root_n, s_sqrt); // sqrt(nodeN + 1e-8) of the root, kept one search ahead
+    double sq_root = sqrt_from_table<TAB>(root_n, s_sqrt); // sqrt(nodeN + 1e-8) of the root, kept one search ahead
 
     // A fresh root is expanded by the first search of the call, which does nothing
     // else (cmcts.cpp:190-243).  That search is taken out of the loop: inside it the
@@ -856,7 +864,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
                 C.cp[k] = P.cpuct * R.p[k]; C.np1[k] = 1.; C.rinv[k] = 1.; C.q[k] = 0.;
             }
             root_n = 0;
-            sq_root = sqrt_from_table(0, s_sqrt);
+            sq_root = sqrt_from_table<TAB>(0, s_sqrt);
             root = slot;
             n_exp++; n_sims++;
             __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): noise loads into the root registers are complete
@@ -912,7 +920,7 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
             }
         }
         root_n += 1;
-        sq_root = sqrt_from_table(root_n, s_sqrt); // for the next search: the table read overlaps this one
+        sq_root = sqrt_from_table<TAB>(root_n, s_sqrt); // for the next search: the table read overlaps this one
 
         int depth = 0;           // path entries below the root
         int parent_slot = root;  // node that will own the link to a new child
@@ -950,9 +958,9 @@ __global__ __launch_bounds__(64 * WPT) void k_simulate_fused(AzParams P, AzFused
 #pragma unroll
                     for (int k = 0; k < E; k++)
                         asm volatile("" : "+v"(nx.n[k]), "+v"(nx.link[k]), "+v"(nx.w[k]), "+v"(nx.p[k]));
-                    pk = select_pick<WPT, E>(nx, fresh, sqrt_from_table(nn, s_sqrt), s.occ, P.cpuct, tid, s_slots, phase);
+                    pk = select_pick<WPT, E>(nx, fresh, sqrt_from_table<TAB>(nn, s_sqrt), s.occ, P.cpuct, tid, s_slots, phase);
                 } else {
-                    pk = select_pick<WPT, E>(nd, fresh, sqrt_from_table(nn, s_sqrt), s.occ, P.cpuct, tid, s_slots, phase);
+                    pk = select_pick<WPT, E>(nd, fresh, sqrt_from_table<TAB>(nn, s_sqrt), s.occ, P.cpuct, tid, s_slots, phase);
                 }
                 STAMP(3);
                 if (AZ_UNLIKELY(pk.a < 0)) {
@@ -1639,14 +1647,24 @@ int l_simulate_fused(const AzParams &P, const AzFusedArgs &A, void *stream)
     }
     const bool identity_mix = P.eps == 0. && P.noise == nullptr;
     const bool uniform = A.eval_kind == AZ_EVAL_UNIFORM;
-    if (uniform && identity_mix)
-        hipLaunchKernelGGL((k_simulate_fused<1, AZ_EVAL_UNIFORM, 0>), grid, dim3(64), 0, st, P, A);
-    else if (uniform)
-        hipLaunchKernelGGL((k_simulate_fused<1, AZ_EVAL_UNIFORM, 1>), grid, dim3(64), 0, st, P, A);
-    else if (identity_mix)
-        hipLaunchKernelGGL((k_simulate_fused<1, AZ_EVAL_HASH, 0>), grid, dim3(64), 0, st, P, A);
-    else
-        hipLaunchKernelGGL((k_simulate_fused<1, AZ_EVAL_HASH, 1>), grid, dim3(64), 0, st, P, A);
+    // the lean form (see k_simulate_fused) where it measured faster: more trees than the chip has SIMDs,
+    // and the hash evaluator at any width; AzFusedArgs::lean overrides the choice
+    static const int simds = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return 4 * cus;
+    }();
+    const bool lean = A.lean >= 0 ? A.lean != 0 : (!uniform || P.n_trees > simds);
+#define AZ_FUSED_LAUNCH(EV, MX)                                                                                   \
+    do {                                                                                                          \
+        if (lean) hipLaunchKernelGGL((k_simulate_fused<1, EV, MX, true>), grid, dim3(64), 0, st, P, A);           \
+        else hipLaunchKernelGGL((k_simulate_fused<1, EV, MX, false>), grid, dim3(64), 0, st, P, A);               \
+    } while (0)
+    if (uniform && identity_mix) AZ_FUSED_LAUNCH(AZ_EVAL_UNIFORM, 0);
+    else if (uniform) AZ_FUSED_LAUNCH(AZ_EVAL_UNIFORM, 1);
+    else if (identity_mix) AZ_FUSED_LAUNCH(AZ_EVAL_HASH, 0);
+    else AZ_FUSED_LAUNCH(AZ_EVAL_HASH, 1);
+#undef AZ_FUSED_LAUNCH
     return launch_status();
 }
 int l_select(const AzParams &P, float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask, unsigned *d_clear_mask, void *stream)

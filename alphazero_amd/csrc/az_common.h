@@ -94,6 +94,9 @@ struct AzShapeOps {
                   void *stream);
     int (*expand_backup)(const AzParams &, const float *d_value, const float *d_prior,
                          int prior_is_log, void *stream);
+    // expand_backup of one search step and select of the next in one launch
+    int (*backup_select)(const AzParams &, const float *d_value, const float *d_prior, int prior_is_log, float *d_boards,
+                         int *d_leaf_kind, unsigned *d_expand_mask, unsigned *d_clear_mask, void *stream);
     int (*make_move)(const AzParams &, const int *d_actions, void *stream);
     int (*clear)(const AzParams &, const unsigned char *d_mask, void *stream);
     int (*select_greedy)(const AzParams &, int *d_actions, void *stream);

@@ -543,13 +543,21 @@ static int simulate_net_steps(az_engine *e, int n, const float *d_params, int fr
         // a new worker builds a new generator (cmcts.cpp:132-133): the noise stream restarts
         HIP_TRY(hipMemset2DAsync((char *)e->P.trees + offsetof(AzTree, noise_row), sizeof(AzTree), 0, sizeof(int),
                                  e->n_trees, (hipStream_t)stream));
+        // per search: select, network, expand + backup; the backup of a search and the select of the
+        // worker's next search share a launch
+        if (e->ops->select(e->P, boards, kinds, mask[step & 1], mask[(step + 1) & 1], stream))
+            return fail(AZ_ERR_HIP, "select launch failed");
         for (int i = 0; i < per; i++) {
             unsigned *cur = mask[step & 1], *other = mask[(step + 1) & 1];
             step++;
-            if (e->ops->select(e->P, boards, kinds, cur, other, stream)) return fail(AZ_ERR_HIP, "select launch failed");
             if (int rc = az_net_eval_masked(e->shape, e->n_trees, boards, kinds, cur, d_params, front, pol, val, value, logp, stream))
                 return fail(rc, "network evaluation launch failed");
-            if (e->ops->expand_backup(e->P, value, logp, 1, stream)) return fail(AZ_ERR_HIP, "expand_backup launch failed");
+            if (i + 1 < per) { // (the next search fills `other` and clears `cur` for the one after it)
+                if (e->ops->backup_select(e->P, value, logp, 1, boards, kinds, other, cur, stream))
+                    return fail(AZ_ERR_HIP, "backup_select launch failed");
+            } else if (e->ops->expand_backup(e->P, value, logp, 1, stream)) {
+                return fail(AZ_ERR_HIP, "expand_backup launch failed");
+            }
         }
     }
     return AZ_OK;

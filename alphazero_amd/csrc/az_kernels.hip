@@ -1093,12 +1093,10 @@ __global__ __launch_bounds__(64 * WPT) AZ_FUSED_ATTR void k_simulate_fused(AzPar
 // d_expand_mask (may be null): one bit per tree, set here when the leaf is to be expanded, for an evaluator
 // that wants the list of those trees without scanning the codes; d_clear_mask: the mask of the step
 // before, which nobody reads any more, zeroed here for the step after (the caller alternates two masks).
-__global__ __launch_bounds__(64) void k_select(AzParams P, float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask,
-                                               unsigned *d_clear_mask)
+__device__ __forceinline__ void select_body(const AzParams &P, int tree, int lane, float *d_boards, int *d_leaf_kind,
+                                            unsigned *d_expand_mask, unsigned *d_clear_mask)
 {
     constexpr int E = EPL;
-    const int tree = blockIdx.x;
-    const int lane = threadIdx.x;
     AzTree *T = &P.trees[tree];
     if (d_clear_mask != nullptr && lane == 0 && (tree & 31) == 0) d_clear_mask[(tree >> 5) * AZ_MASK_STRIDE] = 0u;
     if (uni(T->active) == 0 || uni(T->err) != 0) {
@@ -1159,16 +1157,22 @@ __global__ __launch_bounds__(64) void k_select(AzParams P, float *d_boards, int 
         if (d_expand_mask != nullptr && kind == AZ_LEAF_EXPAND) atomicOr(&d_expand_mask[(tree >> 5) * AZ_MASK_STRIDE], 1u << (tree & 31));
     }
 }
+__global__ __launch_bounds__(64) void k_select(AzParams P, float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask,
+                                               unsigned *d_clear_mask)
+{
+    select_body(P, blockIdx.x, threadIdx.x, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
+}
 
 // ------------------------------------------------------ step: expand + backup
 // Node::set_prior + the backup loop (mcts/src/node.cpp:26-47,75-83;
 // cmcts.cpp:228-231,271-279) for the step prepared by k_select.
-__global__ __launch_bounds__(64) void k_expand_backup(AzParams P, const float *d_value, const float *d_prior,
-                                                       int prior_is_log)
+// Every word a later select of the same wavefront reads back (W, LINK, P, the tree header) is written by
+// the lane that will load it (the action's owner, lane 0 for the header), so k_backup_select needs no
+// fence between its two halves: a lane's load follows its own store in program order.
+__device__ __forceinline__ void expand_backup_body(const AzParams &P, int tree, int lane, const float *d_value,
+                                                   const float *d_prior, int prior_is_log)
 {
     constexpr int E = EPL;
-    const int tree = blockIdx.x;
-    const int lane = threadIdx.x;
     AzTree *T = &P.trees[tree];
     const int kind = uni(T->leaf_kind);
     if (kind == AZ_LEAF_NONE) return;
@@ -1204,10 +1208,12 @@ __global__ __launch_bounds__(64) void k_expand_backup(AzParams P, const float *d
             for (int k = 0; k < E; k++) { nd.n[k] = 0; nd.link[k] = 0; nd.w[k] = 0.; }
             store_stats<E>(P, tree, slot, lane, nd);
         }
+        if (depth > 0) {
+            const int parent_a = uni(pa[depth - 1]);
+            if (lane == owner_of<E>(parent_a)) reinterpret_cast<int *>(rec_ptr(P, tree, parent_slot) + OFF_LINK)[parent_a] = slot + 1;
+        }
         if (lane == 0) {
-            if (depth > 0) {
-                reinterpret_cast<int *>(rec_ptr(P, tree, parent_slot) + OFF_LINK)[pa[depth - 1]] = slot + 1;
-            } else {
+            if (depth == 0) {
                 T->root = slot;
                 T->root_n = 0;
             }
@@ -1223,13 +1229,13 @@ __global__ __launch_bounds__(64) void k_expand_backup(AzParams P, const float *d
         value = unif(T->leaf_value);
         if (lane == 0) T->stats[2] += 1;
     }
-    // backup: lane d handles path level d (independent addresses)
-    for (int d0 = 0; d0 < depth; d0 += 64) {
-        const int d = d0 + lane;
-        if (d < depth) {
+    // backup: the owner of each level's action updates its W (independent addresses)
+    for (int d = 0; d < depth; d++) {
+        const int node = uni(pn[d]), act = uni(pa[d]);
+        if (lane == owner_of<E>(act)) {
             // sign at level d: value flips once per level walking up from the leaf
             const float vd = ((depth - 1 - d) & 1) ? -value : value;
-            double *w = reinterpret_cast<double *>(rec_ptr(P, tree, pn[d]) + OFF_W) + pa[d];
+            double *w = reinterpret_cast<double *>(rec_ptr(P, tree, node) + OFF_W) + act;
             *w += (double)vd + 1.; // node.cpp:80
         }
     }
@@ -1237,6 +1243,20 @@ __global__ __launch_bounds__(64) void k_expand_backup(AzParams P, const float *d
         T->leaf_kind = AZ_LEAF_NONE;
         T->stats[0] += 1;
     }
+}
+__global__ __launch_bounds__(64) void k_expand_backup(AzParams P, const float *d_value, const float *d_prior,
+                                                       int prior_is_log)
+{
+    expand_backup_body(P, blockIdx.x, threadIdx.x, d_value, d_prior, prior_is_log);
+}
+// The backup of one search step and the select of the next in one launch (the network search's inner
+// loop: one launch and one pass over the tree header less per step).
+__global__ __launch_bounds__(64) void k_backup_select(AzParams P, const float *d_value, const float *d_prior,
+                                                       int prior_is_log, float *d_boards, int *d_leaf_kind,
+                                                       unsigned *d_expand_mask, unsigned *d_clear_mask)
+{
+    expand_backup_body(P, blockIdx.x, threadIdx.x, d_value, d_prior, prior_is_log);
+    select_body(P, blockIdx.x, threadIdx.x, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
 }
 
 // first maximum of the root's visit counts, -1 for an idle tree or an unexpanded root
@@ -1673,6 +1693,13 @@ int l_select(const AzParams &P, float *d_boards, int *d_leaf_kind, unsigned *d_e
                        d_clear_mask);
     return launch_status();
 }
+int l_backup_select(const AzParams &P, const float *d_value, const float *d_prior, int is_log, float *d_boards,
+                    int *d_leaf_kind, unsigned *d_expand_mask, unsigned *d_clear_mask, void *stream)
+{
+    hipLaunchKernelGGL(k_backup_select, dim3(P.n_trees), dim3(64), 0, (hipStream_t)stream, P, d_value, d_prior, is_log,
+                       d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
+    return launch_status();
+}
 int l_expand_backup(const AzParams &P, const float *d_value, const float *d_prior, int is_log, void *stream)
 {
     hipLaunchKernelGGL(k_expand_backup, dim3(P.n_trees), dim3(64), 0, (hipStream_t)stream, P, d_value, d_prior,
@@ -1728,7 +1755,7 @@ int l_dirichlet(double *d_table, int rows, double alpha, unsigned long long seed
 extern "C" const AzShapeOps *AZ_CAT(az_shape_ops_, AZ_S)(void)
 {
     static const AzShapeOps ops = {
-        AZ_S, SP, l_simulate_fused, l_select, l_expand_backup, l_make_move, l_clear, l_select_greedy, l_get_counts,
+        AZ_S, SP, l_simulate_fused, l_select, l_expand_backup, l_backup_select, l_make_move, l_clear, l_select_greedy, l_get_counts,
         l_choose_moves, l_dirichlet, l_restart,
     };
     return &ops;

@@ -2158,12 +2158,22 @@ int az_net_eval_masked(int shape, int n, const float *d_boards, const int *d_lea
     // larger boards the Winograd kernel with one wavefront per SIMD (k_net_wide: measured faster than both
     // team kernels at every size from 16x16 to 20x20).  az_net_set_form overrides the choice.
     const int form = g_net_form.load(std::memory_order_relaxed);
-    const bool team = form == AZ_NET_FORM_TEAM;
+    // A batch that leaves CUs idle (one tree behind the cmcts facade, a small arena) is bound by the latency of
+    // one position, not by throughput: a team of wavefronts per position finishes it sooner than one wavefront
+    // (measured per launch at n <= 256: 40 us against 52 us at 15x15, 40 us against 106 us at 20x20; the
+    // one-wavefront kernels win from about 2 positions per CU on, above 15x15 from about 3).
+    static const int cus = [] {
+        int dev = 0, c = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+        return c;
+    }();
+    const bool few = form == AZ_NET_FORM_AUTO && (n <= cus || (shape >= 16 && n <= 2 * cus));
+    const bool team = form == AZ_NET_FORM_TEAM || few;
     const bool wino = form == AZ_NET_FORM_WINOGRAD || (form == AZ_NET_FORM_AUTO && shape >= 12);
     switch (shape) {
 #define AZ_NET_CASE(s)                                                                                                   \
     case s:                                                                                                              \
-        if (s >= 12 && (form == AZ_NET_FORM_WIDE || (form == AZ_NET_FORM_AUTO && s >= 16)))                              \
+        if (s >= 12 && (form == AZ_NET_FORM_WIDE || (form == AZ_NET_FORM_AUTO && s >= 16 && !few)))                      \
             return launch_wide<(s >= 12 ? s : 12)>(d_boards, d_leaf_kind, d_expand_mask, n, d_params, front_layers,      \
                                                    policy_layers, value_layers, d_value, d_logp, st);                    \
         if (s <= 15 && !team && wino)                                                                                    \

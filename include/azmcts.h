@@ -318,7 +318,8 @@ int az_aug_unique_average(int shape, int n_unique, const int *d_members, const i
  * 16 conv channels (config.py:12-15), layer counts as given. */
 int az_net_param_floats(int front_layers, int policy_layers, int value_layers);
 /* Which kernel az_net_eval runs (no counterpart in the reference; for tuning and for
- * tests that compare the forms): AUTO = by board size (one wavefront per position and two
+ * tests that compare the forms): AUTO = the direct-form team kernel for batches of at most one
+ * position per CU (two above 15x15), otherwise by board size (one wavefront per position and two
  * per SIMD up to 15x15, the 3x3 layers in the Winograd F(2x2,3x3) form from 12x12 on; the
  * Winograd kernel with one wavefront per SIMD above 15x15); DIRECT / WINOGRAD = that form
  * of the 3x3 layers for every size (one wavefront per position up to 15x15, a team of

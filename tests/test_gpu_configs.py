@@ -99,6 +99,8 @@ def test_simulate_net_position_mask_with_idle_and_terminal_leaves(B, S, plies):
 
     sims, size = 40, S * S  # (5x5: the board fills up, searches end on finished games and the games themselves end)
     _, ev = _fused(S, seed=5)
+    # the one-wavefront kernels are the ones that read the mask; batches this small would get the team kernel
+    assert ev.L.az_net_set_form(2 if S <= 15 else 4) == 0  # AZ_NET_FORM_WINOGRAD / AZ_NET_FORM_WIDE
     active = (np.arange(B) % 5 != 2).astype(np.uint8)
     engs = []
     for _ in range(2):
@@ -135,6 +137,7 @@ def test_simulate_net_position_mask_with_idle_and_terminal_leaves(B, S, plies):
         active = (active.astype(bool) & (a.get_states()[2] == -1.0)).astype(np.uint8)
         for eng in (a, b):
             eng.set_active(active)
+    ev.L.az_net_set_form(0)
     if S == 5:
         assert terminals > 0 and not active.any()  # searches reached finished games; every game is over
     a.close()

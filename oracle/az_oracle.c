@@ -2,6 +2,17 @@
  * az_oracle.c -- CPU restatement of the reference cmcts engine (see az_oracle.h).
  * TEST INFRASTRUCTURE ONLY: never linked or imported by the product package.
  *
+ * What pins it:
+ *   - the rules (state_*: state.cpp) are PINNED: tests/golden/rules_S*.json are answers of the
+ *     reference's own state.cpp, compiled unmodified (oracle/Makefile `ref`), and this file must
+ *     reproduce them (tests/test_oracle_rules.py);
+ *   - the caller loops built on it are pinned by records the reference's own self_play_game /
+ *     eval_game produced (tests/golden/caller_games.npz);
+ *   - the tree arithmetic (node_*: node.cpp, search / azo_simulate: cmcts.cpp) is PARITY UNPINNED by
+ *     execution: node.cpp and cmcts.cpp include GSL headers the build image lacks and cannot be
+ *     compiled there.  That part follows the source text line by line (citations at every function)
+ *     and reproduces the facts recorded from the real reference (tests/test_oracle_search.py).
+ *
  * All reference citations are relative to /root/reference/mcts/src/.
  * Build:  gcc -O2 -ffp-contract=off -fPIC -shared -pthread az_oracle.c -o libaz_oracle.so -lm
  * (-ffp-contract=off: the reference is built without optimisation for baseline

@@ -419,6 +419,38 @@ def secondary_games(torch, dev_index, mode, games=4096, shape=SHAPE, sims=100, t
         return {"workload": mode, "error": f"{type(e).__name__}: {e}"}
 
 
+def one_tree_latency(torch, dev_index, sims=800):
+    """The reference's own usage: ONE tree behind the cmcts facade (src/self_play.py:156,
+    src/pbrain-server.py:66): wall time of simulate(800) with the reference network at 15x15 and
+    20x20.  Latency-bound (one position per evaluation); not a throughput figure."""
+    out = {"workload": f"one tree, simulate({sims}) with the reference net (seed 0), eps=0.25, cpuct=4"}
+    try:
+        from alphazero_amd import selfplay as sp
+        from alphazero_amd.evaluator import FusedNetEvaluator
+        from alphazero_amd.model import PolicyValueNet
+
+        dev = torch.device("cuda", dev_index)
+        for shape in (15, 20):
+            torch.manual_seed(0)
+            ev = FusedNetEvaluator(PolicyValueNet(shape).eval(), shape, dev)
+            tb = sp.TreeBatch(1, shape, ev, cpuct=CPUCT, eps=0.25, nodes_per_tree=4 * sims + 64, device=dev_index)
+            try:
+                tb.make_move(np.array([shape * shape // 2], np.int32))
+                tb.simulate(32)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                tb.simulate(sims)
+                torch.cuda.synchronize(dev)
+                dt = time.perf_counter() - t0
+                out[f"ms_per_simulate_{shape}x{shape}"] = dt * 1e3
+                out[f"us_per_search_{shape}x{shape}"] = dt / sims * 1e6
+            finally:
+                tb.close()
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
 def config4_share(torch, E, dev_index):
     """One GPU's share of config 4 (65,536 games of 20x20 over 8 GPUs = 8192 per GPU):
     the network-evaluated search at that width; 200 search steps timed."""
@@ -474,7 +506,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--only", default=None,
                     help="run one secondary workload alone and print its record (for profiling): "
-                         + ", ".join(list(HASH_WORKLOADS) + ["config3", "config4_share", "config3_games", "config3_stream", "config5_share"]))
+                         + ", ".join(list(HASH_WORKLOADS) + ["config3", "config4_share", "config3_games", "config3_stream", "config5_share", "config1_one_tree"]))
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -520,6 +552,7 @@ def main():
                else secondary_games(torch, dev_index, "selfplay") if args.only == "config3_games"
                else secondary_games(torch, dev_index, "selfplay", games=16384, slots=8192) if args.only == "config3_stream"
                else secondary_games(torch, dev_index, "arena") if args.only == "config5_share"
+               else one_tree_latency(torch, dev_index) if args.only == "config1_one_tree"
                else secondary_hash(torch, E, dev_index, args.only, *HASH_WORKLOADS[args.only], traffic))
         print(json.dumps(rec), flush=True)
         return
@@ -585,6 +618,7 @@ def main():
                 "config3_games": secondary_games(torch, dev_index, "selfplay"),
                 "config3_stream": secondary_games(torch, dev_index, "selfplay", games=16384, slots=8192),
                 "config5_share": secondary_games(torch, dev_index, "arena"),
+                "config1_one_tree": one_tree_latency(torch, dev_index),
             }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -35,7 +35,10 @@ constexpr int CH = 16;  // conv channels of the reference configuration (config.
 constexpr int CIN = 2;  // input planes (config.py:12)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int S> struct Geo {
+// NWF = 0: the team size chosen for throughput (below); NWF > 0: that many wavefronts per position (as far
+// as the board has tiles), for launches that are bound by the latency of one position
+template <int S_, int NWF = 0> struct Geo {
+    static constexpr int S = S_;
     static constexpr int SIZE = S * S;
     static constexpr int ROW = S + 2;               // one halo column on each side
     static constexpr int PLANE = ROW * ROW;
@@ -50,8 +53,9 @@ template <int S> struct Geo {
     // Workgroups per CU and wavefronts per workgroup: the kernel is built for two wavefronts
     // per SIMD (256 registers each), i.e. eight per CU: four workgroups of two where the LDS
     // holds four positions, else two workgroups of four.
-    static constexpr int WGS = (158 * 1024) / FIXED_BYTES >= 4 ? 4 : 2;
-    static constexpr int NW0 = WGS == 4 ? 2 : 4;
+    static constexpr int WGS_FIT = (158 * 1024) / FIXED_BYTES;
+    static constexpr int WGS = NWF > 0 ? (8 / NWF < 1 ? 1 : (8 / NWF > WGS_FIT ? WGS_FIT : 8 / NWF)) : (WGS_FIT >= 4 ? 4 : 2);
+    static constexpr int NW0 = NWF > 0 ? NWF : (WGS == 4 ? 2 : 4);
     static constexpr int NW = NW0 > NT ? NT : NW0;
     static constexpr int TQ = NT / NW, TR = NT % NW; // wavefronts below TR take TQ + 1 tiles
     static constexpr int NTHR = 64 * NW;
@@ -240,9 +244,9 @@ template <int NTMAX> struct TileMap {
     int last_valid; // pixels of the lane's four that exist in the board's last, partial tile
     int crd, cwr;   // the same for the corner pixel of a board of 16k+1 pixels
 };
-template <int S> __device__ __forceinline__ void make_tile_map(int wave, int lane, TileMap<Geo<S>::TQ + 1> &m)
+template <class G> __device__ __forceinline__ void make_tile_map(int wave, int lane, TileMap<G::TQ + 1> &m)
 {
-    using G = Geo<S>;
+    constexpr int S = G::S;
     const int co = lane & 15, kq = lane >> 4;
     m.tile0 = wave < G::TR ? wave * (G::TQ + 1) : G::TR * (G::TQ + 1) + (wave - G::TR) * G::TQ;
 #pragma unroll
@@ -271,11 +275,10 @@ template <int S> __device__ __forceinline__ void make_tile_map(int wave, int lan
 // CORNERW: this wavefront also computes the board's last pixel (boards of 16k+1 pixels).
 // MODE_VALUE_SUM: nothing is written; returns this lane's sum of its outputs (the
 // value head only needs the board sums per channel).
-template <int S, int KSTEPS, int NTW, bool CORNERW, int MODE>
+template <class G, int KSTEPS, int NTW, bool CORNERW, int MODE>
 __device__ __forceinline__ float conv3x3(const float *src, float *dst, const LayerRegs<KSTEPS> &w, const int (&off0)[5],
-                                         const TileMap<Geo<S>::TQ + 1> &m, int lane)
+                                         const TileMap<G::TQ + 1> &m, int lane)
 {
-    using G = Geo<S>;
     const int kq = lane >> 4;
     // (the batch-norm scale is folded into the weights by the host: the accumulators start
     // from the shift and the epilogue is the ReLU alone)
@@ -365,28 +368,26 @@ __device__ __forceinline__ float conv3x3(const float *src, float *dst, const Lay
 
 // the wavefront's share of a layer: wavefronts below TR take TQ + 1 tiles, the last
 // wavefront takes the corner pixel
-template <int S, int KSTEPS, int MODE>
+template <class G, int KSTEPS, int MODE>
 __device__ __forceinline__ float conv_layer(const float *src, float *dst, const LayerRegs<KSTEPS> &w, const int (&off0)[5],
-                                            const TileMap<Geo<S>::TQ + 1> &m, int wave, int lane)
+                                            const TileMap<G::TQ + 1> &m, int wave, int lane)
 {
-    using G = Geo<S>;
     if constexpr (G::TR != 0) {
-        if (wave < G::TR) return conv3x3<S, KSTEPS, G::TQ + 1, false, MODE>(src, dst, w, off0, m, lane);
+        if (wave < G::TR) return conv3x3<G, KSTEPS, G::TQ + 1, false, MODE>(src, dst, w, off0, m, lane);
     }
     if constexpr (G::CORNER) {
-        if (wave == G::NW - 1) return conv3x3<S, KSTEPS, G::TQ, true, MODE>(src, dst, w, off0, m, lane);
+        if (wave == G::NW - 1) return conv3x3<G, KSTEPS, G::TQ, true, MODE>(src, dst, w, off0, m, lane);
     }
-    return conv3x3<S, KSTEPS, G::TQ, false, MODE>(src, dst, w, off0, m, lane);
+    return conv3x3<G, KSTEPS, G::TQ, false, MODE>(src, dst, w, off0, m, lane);
 }
 
 // Policy head, first half: the 3x3 convolution to one channel is split into a 1x1
 // product on the matrix cores, T[tap][q] = sum_ci w[tap][ci] * src[ci][q] (N = the 9 taps),
 // written as 9 planes of `tb`; the logit of pixel p is then bias + sum_tap T[tap][p + offset(tap)].
-template <int S, int NTW, bool CORNERW>
+template <class G, int NTW, bool CORNERW>
 __device__ __forceinline__ void policy_taps(const float *src, float *tb, const float (&bp)[4],
-                                            const TileMap<Geo<S>::TQ + 1> &m, int lane)
+                                            const TileMap<G::TQ + 1> &m, int lane)
 {
-    using G = Geo<S>;
     const int n = lane & 15, kq = lane >> 4;
     f32x4 acc[NTW];
 #pragma unroll
@@ -413,29 +414,27 @@ __device__ __forceinline__ void policy_taps(const float *src, float *tb, const f
         if (kq == 0 && n < 9) tb[m.cwr] = v;
     }
 }
-template <int S>
+template <class G>
 __device__ __forceinline__ void policy_taps_layer(const float *src, float *tb, const float (&bp)[4],
-                                                  const TileMap<Geo<S>::TQ + 1> &m, int wave, int lane)
+                                                  const TileMap<G::TQ + 1> &m, int wave, int lane)
 {
-    using G = Geo<S>;
     if constexpr (G::TR != 0) {
-        if (wave < G::TR) return policy_taps<S, G::TQ + 1, false>(src, tb, bp, m, lane);
+        if (wave < G::TR) return policy_taps<G, G::TQ + 1, false>(src, tb, bp, m, lane);
     }
     if constexpr (G::CORNER) {
-        if (wave == G::NW - 1) return policy_taps<S, G::TQ, true>(src, tb, bp, m, lane);
+        if (wave == G::NW - 1) return policy_taps<G, G::TQ, true>(src, tb, bp, m, lane);
     }
-    policy_taps<S, G::TQ, false>(src, tb, bp, m, lane);
+    policy_taps<G, G::TQ, false>(src, tb, bp, m, lane);
 }
 
 // Policy head, second half: gather of the 9 partial planes + bias, log-softmax over the board
-template <int S>
+template <class G>
 __device__ __forceinline__ void policy_softmax(const float *tb, float bias, float *red, float *logit, float *logp_row,
                                                int tid, int wave, int lane)
 {
-    using G = Geo<S>;
     float lmax = -INFINITY;
     for (int p = tid; p < G::SIZE; p += G::NTHR) {
-        const int ctr = pix_index<S>(p);
+        const int ctr = pix_index<G::S>(p);
         float acc = bias;
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) acc += tb[tap * G::PS + ctr + (tap / 3 - 1) * G::ROW + (tap % 3 - 1)];
@@ -462,11 +461,10 @@ __device__ __forceinline__ void policy_softmax(const float *tb, float bias, floa
     for (int p = tid; p < G::SIZE; p += G::NTHR) logp_row[p] = logit[p] - lse;
 }
 
-template <int S>
-__global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_eval(const float *boards, const int *leaf_kind, int n, const float *prm,
+template <class G>
+__global__ __launch_bounds__(G::NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_eval(const float *boards, const int *leaf_kind, int n, const float *prm,
                                                            int front, int pol, int val, float *value_out, float *logp_out)
 {
-    using G = Geo<S>;
     extern __shared__ float lds[];
     float *F = lds, *W = lds + G::BUF;
     float *red = lds + 2 * G::BUF;     // [16]: two reduction rows of up to 8 wavefronts
@@ -497,7 +495,7 @@ __global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2,
         off0[ks] = (kk & 1) * G::PS + (tap / 3 - 1) * G::ROW + (tap % 3 - 1);
     }
     TileMap<G::TQ + 1> tm;
-    make_tile_map<S>(wave, lane, tm);
+    make_tile_map<G>(wave, lane, tm);
     float bp[4]; // policy head as a B operand: B[k = ci][n = tap]
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) bp[ks] = co < 9 ? p_policy[co * CH + ks * 4 + kq] : 0.f;
@@ -518,14 +516,14 @@ __global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2,
         // the previous position: the 2-plane layer never reads them)
         for (int i = tid; i < CIN * G::SIZE; i += G::NTHR) {
             const int c = i / G::SIZE, p = i - c * G::SIZE;
-            W[c * G::PS + pix_index<S>(p)] = boards[(size_t)pos * CIN * G::SIZE + i];
+            W[c * G::PS + pix_index<G::S>(p)] = boards[(size_t)pos * CIN * G::SIZE + i];
         }
         // The parameters of the next convolution are requested one layer ahead, so
         // their L2 latency runs under the current layer's matrix instructions.
         LayerRegs<36> wq, wn;
         if (nl > 0) load_layer<36>(layer_params(0), lane, wq);
         __syncthreads();
-        conv_layer<S, 5, MODE_WRITE>(W, F, w0, off0, tm, wave, lane);
+        conv_layer<G, 5, MODE_WRITE>(W, F, w0, off0, tm, wave, lane);
         __syncthreads();
         float vpart = 0.f; // this lane's share of the value head's sum
         bool v_done = false;
@@ -538,17 +536,17 @@ __global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2,
             float *dst = trunk ? F : W;
             if (val > 0 && e == front - 1 + val - 1) {
                 // last layer of the value branch: only the per-channel board sums are needed
-                vpart = wv * conv_layer<S, 36, MODE_VALUE_SUM>(src, dst, wq, off0, tm, wave, lane);
+                vpart = wv * conv_layer<G, 36, MODE_VALUE_SUM>(src, dst, wq, off0, tm, wave, lane);
                 v_done = true;
             } else {
-                conv_layer<S, 36, MODE_WRITE>(src, dst, wq, off0, tm, wave, lane);
+                conv_layer<G, 36, MODE_WRITE>(src, dst, wq, off0, tm, wave, lane);
             }
             __syncthreads();
             if (e + 1 < nl) wq = wn;
         }
         if (!v_done) { // no value branch: the head reads the trunk output
             for (int p = tid; p < G::SIZE; p += G::NTHR) {
-                const int ctr = pix_index<S>(p);
+                const int ctr = pix_index<G::S>(p);
 #pragma unroll
                 for (int ci = 0; ci < CH; ci++) vpart += p_value[ci] * F[ci * G::PS + ctr];
             }
@@ -559,7 +557,7 @@ __global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2,
         // ---- policy head: partial planes on the matrix cores, gather + log-softmax
         const float *hsrc = pol > 0 ? W : F;
         float *tb = pol > 0 ? F : W;
-        policy_taps_layer<S>(hsrc, tb, bp, tm, wave, lane);
+        policy_taps_layer<G>(hsrc, tb, bp, tm, wave, lane);
         if (lane == 0) red[wave] = vpart;
         __syncthreads();
         if (tid == 0) { // ---- value head: board average of the 1x1 convolution + bias, tanh
@@ -569,7 +567,7 @@ __global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2,
             value_out[pos] = tanhf(vt / (float)G::SIZE + v_bias);
         }
         __syncthreads(); // red is reused by the softmax
-        policy_softmax<S>(tb, p_bias, red, logit, logp_out + (size_t)pos * G::SIZE, tid, wave, lane);
+        policy_softmax<G>(tb, p_bias, red, logit, logp_out + (size_t)pos * G::SIZE, tid, wave, lane);
         // No barrier here: every read of tb's planes precedes the two barriers inside the
         // softmax, and the next position first writes W's input planes, which nobody reads
         // at this point (tb == W only when there is no policy branch, and then the gather
@@ -1630,8 +1628,8 @@ __global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2,
             TileMap<G::TQ + 1> tm; // (formed here: the layers need the registers)
             int lo = lane;
             asm volatile("" : "+v"(lo));
-            make_tile_map<S>(wave, lo, tm);
-            policy_taps_layer<S>(hsrc, tb, bp, tm, wave, lane);
+            make_tile_map<G>(wave, lo, tm);
+            policy_taps_layer<G>(hsrc, tb, bp, tm, wave, lane);
         }
         if (lane == 0) red[wave] = vpart;
         __syncthreads();
@@ -1642,7 +1640,7 @@ __global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2,
             value_out[pos] = tanhf(vt / (float)G::SIZE + v_bias);
         }
         __syncthreads(); // red is reused by the softmax
-        policy_softmax<S>(tb, p_bias, red, logit, logp_out + (size_t)pos * G::SIZE, tid, wave, lane);
+        policy_softmax<G>(tb, p_bias, red, logit, logp_out + (size_t)pos * G::SIZE, tid, wave, lane);
         __syncthreads(); // (the dump area overlaps red / logit: the next position's layers wait for the softmax)
     }
 }
@@ -2090,10 +2088,9 @@ template <int S, bool WINO> int launch_solo(const float *boards, const int *leaf
     return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
 }
 
-template <int S> int launch(const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val,
-                            float *value_out, float *logp_out, hipStream_t st)
+template <class G> int launch(const float *boards, const int *leaf_kind, int n, const float *prm, int front, int pol, int val,
+                              float *value_out, float *logp_out, hipStream_t st)
 {
-    using G = Geo<S>;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int grid = cus * G::WGS;
@@ -2103,12 +2100,12 @@ template <int S> int launch(const float *boards, const int *leaf_kind, int n, co
     // largest size the kernel has been opened up to, per device (the attribute is per device)
     static size_t configured[64] = {};
     if (dev < 0 || dev >= 64 || lds_bytes > configured[dev]) {
-        if (hipFuncSetAttribute((const void *)k_net_eval<S>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)k_net_eval<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes) != hipSuccess)
             return AZ_ERR_HIP;
         if (dev >= 0 && dev < 64) configured[dev] = lds_bytes;
     }
-    hipLaunchKernelGGL(k_net_eval<S>, dim3(grid), dim3(G::NTHR), lds_bytes, st, boards, leaf_kind, n, prm, front, pol, val,
+    hipLaunchKernelGGL(k_net_eval<G>, dim3(grid), dim3(G::NTHR), lds_bytes, st, boards, leaf_kind, n, prm, front, pol, val,
                        value_out, logp_out);
     return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
 }
@@ -2160,8 +2157,9 @@ int az_net_eval_masked(int shape, int n, const float *d_boards, const int *d_lea
     const int form = g_net_form.load(std::memory_order_relaxed);
     // A batch that leaves CUs idle (one tree behind the cmcts facade, a small arena) is bound by the latency of
     // one position, not by throughput: a team of wavefronts per position finishes it sooner than one wavefront
-    // (measured per launch at n <= 256: 40 us against 52 us at 15x15, 40 us against 106 us at 20x20; the
-    // one-wavefront kernels win from about 2 positions per CU on, above 15x15 from about 3).
+    // (measured per launch at n <= 256, eight wavefronts per position: 25 us against 52 us at 15x15, 37 us
+    // against 106 us at 20x20; the one-wavefront kernels win from about 2 positions per CU on, above 15x15
+    // from about 3).
     static const int cus = [] {
         int dev = 0, c = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
@@ -2185,7 +2183,10 @@ int az_net_eval_masked(int shape, int n, const float *d_boards, const int *d_lea
         if (s >= 16 && form == AZ_NET_FORM_WINOGRAD)                                                                     \
             return launch_team_wino<(s >= 16 ? s : 16)>(d_boards, d_leaf_kind, n, d_params, front_layers, policy_layers, \
                                                        value_layers, d_value, d_logp, st);                              \
-        return launch<s>(d_boards, d_leaf_kind, n, d_params, front_layers, policy_layers, value_layers, d_value, d_logp, st);
+        if (few && n <= cus) /* one position per CU at most: eight wavefronts per position */                            \
+            return launch<Geo<s, 8>>(d_boards, d_leaf_kind, n, d_params, front_layers, policy_layers, value_layers,      \
+                                     d_value, d_logp, st);                                                               \
+        return launch<Geo<s>>(d_boards, d_leaf_kind, n, d_params, front_layers, policy_layers, value_layers, d_value, d_logp, st);
 #ifdef AZ_NET_DEV_SHAPE // (development builds: one board size only)
         AZ_NET_CASE(AZ_NET_DEV_SHAPE)
 #else

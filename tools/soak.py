@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Longer randomized differential run than the test suite's fixed-seed sweeps: the fused search
+(both kernel forms) and the network search's mask path against the oracle / the three-step path.
+
+    python tools/soak.py [--seconds 120] [--seed 1]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    import test_gpu_search as TS
+    import test_gpu_configs as TC
+
+    rng = np.random.default_rng(args.seed)
+    t0, n_fused, n_net = time.time(), 0, 0
+    while time.time() - t0 < args.seconds:
+        S = int(rng.integers(5, 21))
+        sims = int(rng.integers(20, 700))
+        os.environ["AZ_FUSED_LEAN"] = str(int(rng.integers(0, 2)))
+        TS._play_fused(S, B=int(rng.integers(1, 6)), sims=sims, plies=int(rng.integers(2, 6)),
+                       ev_kind=str(rng.choice(["uniform", "hash"])), eps=float(rng.choice([0.0, 0.1, 0.25, 1.0])),
+                       cpuct=float(rng.choice([0.0, 0.5, 4.0, 10.0])), nodes=sims * 8 + 64, seed=int(rng.integers(1, 1000)))
+        n_fused += 1
+        if n_fused % 8 == 0:
+            B, S2 = int(rng.integers(2, 200)), int(rng.choice([5, 6, 7, 9, 13, 15, 16, 20]))
+            TC.test_simulate_net_position_mask_with_idle_and_terminal_leaves(B, S2, int(rng.integers(2, 6)) if S2 != 5 else 24)
+            n_net += 1
+        print(f"\r{n_fused} fused, {n_net} network configurations ok", end="", flush=True)
+    print()
+
+
+if __name__ == "__main__":
+    main()

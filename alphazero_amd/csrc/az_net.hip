@@ -1580,7 +1580,6 @@ __global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2,
         wino_team_layer<S, 1, false, MODE_WRITE>(W, F, dump, u0, nullptr, u0sh, wave, lane);
         __syncthreads();
         float vpart = 0.f; // this lane's share of the value head's sum
-        bool v_done = false;
         // Buffers: a layer writes the buffer it does not read wherever that one is free (no wait between
         // a wavefront's matrix work and its stores); only the later layers of the value branch run in
         // place, while the other buffer still holds the trunk output for the policy branch.
@@ -1592,7 +1591,6 @@ __global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
                 for (int ci = 0; ci < CH; ci++) vpart += p_value[ci] * trunk_out[ci * G::PS + ctr];
             }
-            v_done = true;
             __syncthreads();
         };
         if (val == 0 && front == 1) value_from_trunk();
@@ -1608,7 +1606,6 @@ __global__ __launch_bounds__(Geo<S>::NTHR) __attribute__((amdgpu_waves_per_eu(2,
             if (val > 0 && e == front - 1 + val - 1) {
                 // last layer of the value branch: only the per-channel board sums are needed
                 vpart = wv * wino_team_layer<S, 4, true, MODE_VALUE_SUM>(src, dst, dump, u, nextp, sh, wave, lane);
-                v_done = true;
             } else {
                 if (src == dst) wino_team_layer<S, 4, true, MODE_WRITE, true>(src, dst, dump, u, nextp, sh, wave, lane);
                 else wino_team_layer<S, 4, true, MODE_WRITE, false>(src, dst, dump, u, nextp, sh, wave, lane);

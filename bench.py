@@ -348,6 +348,14 @@ def secondary_net(torch, E, dev_index, trees=8192, shape=SHAPE, sims=SIMS, label
                 "select_ms_per_step": t_sel, "expand_backup_ms_per_step": t_exp,
                 "step_over_kernel_sum": elapsed / sims * 1e3 / (t_sel + t_net + t_exp),
                 "mean_select_depth": st["select_calls"] / max(1, st["sims"]),
+                # the two tree kernels of a search step (az_select + az_expand_backup, timed as separate
+                # launches) against the HBM roofline, with the same algorithmic byte model as the headline
+                "tree_roofline": (lambda d, t: {
+                    "bound": "hbm", "kernel": "k_select + k_expand_backup", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                    "bytes_per_sim": algorithmic_bytes_per_sim(d, shape * shape),
+                    "achieved": trees * algorithmic_bytes_per_sim(d, shape * shape) / (t / 1e3) / 1e9,
+                    "frac": trees * algorithmic_bytes_per_sim(d, shape * shape) / (t / 1e3) / 1e9 / HBM_PEAK_GBS,
+                })(st["select_calls"] / max(1, st["sims"]), t_sel + t_exp),
                 "evaluator_roofline": {"bound": "mfma", "kernel": kname,
                                        "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TF, "achieved": executed_tf,
                                        "frac": executed_tf / MFMA_F32_PEAK_TF,

@@ -97,6 +97,10 @@ struct AzShapeOps {
     // expand_backup of one search step and select of the next in one launch
     int (*backup_select)(const AzParams &, const float *d_value, const float *d_prior, int prior_is_log, float *d_boards,
                          int *d_leaf_kind, unsigned *d_expand_mask, unsigned *d_clear_mask, void *stream);
+    // the whole network search of a simulate call in one launch (at most one tree per CU): th_num workers of
+    // `per` searches each, d_params as az_net_eval takes them
+    int (*net_search)(const AzParams &, int th_num, int per, const float *d_params, int front_layers, int policy_layers,
+                      int value_layers, void *stream);
     int (*make_move)(const AzParams &, const int *d_actions, void *stream);
     int (*clear)(const AzParams &, const unsigned char *d_mask, void *stream);
     int (*select_greedy)(const AzParams &, int *d_actions, void *stream);
@@ -110,6 +114,9 @@ struct AzShapeOps {
 // Words of the expand masks are AZ_MASK_STRIDE words apart: the trees' atomic ORs then spread over four times
 // as many cache lines (8192 atomics on eight lines cost k_select 5 us), while a reader still fetches only 4 KB.
 #define AZ_MASK_STRIDE 4
+
+// the kernel form az_net_eval is set to (AZ_NET_FORM_*; az_net.hip)
+int az_net_get_form();
 
 // az_net_eval (az_net.hip) with the bit mask k_select fills (one bit per position, word w at index
 // w * AZ_MASK_STRIDE, set = evaluate it; null: the codes are scanned as az_net_eval does).  Internal to the

@@ -539,6 +539,19 @@ static int simulate_net_steps(az_engine *e, int n, const float *d_params, int fr
         else if (n % th_num == 0) per = n / th_num;
         else per = n / th_num + 1;
     }
+    // At most one tree per CU: the launches of a search step would cost more than their work, so the whole
+    // call is one launch (k_net_search; same arithmetic).  AZ_NET_SEARCH=0 in the environment, or a kernel
+    // form forced through az_net_set_form, keeps the stepped launches.
+    {
+        int cus = 0;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device);
+        const char *sw = getenv("AZ_NET_SEARCH");
+        if (e->n_trees <= cus && az_net_get_form() == AZ_NET_FORM_AUTO && !(sw && atoi(sw) == 0)) {
+            if (e->ops->net_search(e->P, th_num, per, d_params, front, pol, val, stream))
+                return fail(AZ_ERR_HIP, "net_search launch failed");
+            return AZ_OK;
+        }
+    }
     for (int w = 0; w < th_num; w++) {
         // a new worker builds a new generator (cmcts.cpp:132-133): the noise stream restarts
         HIP_TRY(hipMemset2DAsync((char *)e->P.trees + offsetof(AzTree, noise_row), sizeof(AzTree), 0, sizeof(int),

@@ -28,6 +28,7 @@
 
 #include "../../include/azmcts.h"
 #include "az_common.h"
+#include "az_net_team.h"
 
 #pragma clang fp contract(off)
 
@@ -1093,14 +1094,16 @@ __global__ __launch_bounds__(64 * WPT) AZ_FUSED_ATTR void k_simulate_fused(AzPar
 // d_expand_mask (may be null): one bit per tree, set here when the leaf is to be expanded, for an evaluator
 // that wants the list of those trees without scanning the codes; d_clear_mask: the mask of the step
 // before, which nobody reads any more, zeroed here for the step after (the caller alternates two masks).
-__device__ __forceinline__ void select_body(const AzParams &P, int tree, int lane, float *d_boards, int *d_leaf_kind,
+// out: the tree's index in the output arrays (d_boards, d_leaf_kind, the masks): the tree itself for the
+// batched kernels, 0 for a caller that hands in buffers of its own
+__device__ __forceinline__ void select_body(const AzParams &P, int tree, int out, int lane, float *d_boards, int *d_leaf_kind,
                                             unsigned *d_expand_mask, unsigned *d_clear_mask)
 {
     constexpr int E = EPL;
     AzTree *T = &P.trees[tree];
-    if (d_clear_mask != nullptr && lane == 0 && (tree & 31) == 0) d_clear_mask[(tree >> 5) * AZ_MASK_STRIDE] = 0u;
+    if (d_clear_mask != nullptr && lane == 0 && (out & 31) == 0) d_clear_mask[(out >> 5) * AZ_MASK_STRIDE] = 0u;
     if (uni(T->active) == 0 || uni(T->err) != 0) {
-        if (lane == 0) { T->leaf_kind = AZ_LEAF_NONE; d_leaf_kind[tree] = AZ_LEAF_NONE; }
+        if (lane == 0) { T->leaf_kind = AZ_LEAF_NONE; d_leaf_kind[out] = AZ_LEAF_NONE; }
         return;
     }
     WState s;
@@ -1146,21 +1149,21 @@ __device__ __forceinline__ void select_body(const AzParams &P, int tree, int lan
         nn = pk.n - 1;
     }
     if (err) kind = AZ_LEAF_NONE;
-    if (kind == AZ_LEAF_EXPAND) write_board(s, d_boards + (size_t)tree * 2 * SIZE, lane);
+    if (kind == AZ_LEAF_EXPAND) write_board(s, d_boards + (size_t)out * 2 * SIZE, lane);
     if (lane == 0) {
         T->leaf_kind = kind;
         T->path_len = depth;
         T->leaf_value = leaf_value;
         T->stats[3] += n_sel;
         if (err) T->err = err;
-        d_leaf_kind[tree] = kind;
-        if (d_expand_mask != nullptr && kind == AZ_LEAF_EXPAND) atomicOr(&d_expand_mask[(tree >> 5) * AZ_MASK_STRIDE], 1u << (tree & 31));
+        d_leaf_kind[out] = kind;
+        if (d_expand_mask != nullptr && kind == AZ_LEAF_EXPAND) atomicOr(&d_expand_mask[(out >> 5) * AZ_MASK_STRIDE], 1u << (out & 31));
     }
 }
 __global__ __launch_bounds__(64) void k_select(AzParams P, float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask,
                                                unsigned *d_clear_mask)
 {
-    select_body(P, blockIdx.x, threadIdx.x, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
+    select_body(P, blockIdx.x, blockIdx.x, threadIdx.x, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
 }
 
 // ------------------------------------------------------ step: expand + backup
@@ -1169,7 +1172,7 @@ __global__ __launch_bounds__(64) void k_select(AzParams P, float *d_boards, int 
 // Every word a later select of the same wavefront reads back (W, LINK, P, the tree header) is written by
 // the lane that will load it (the action's owner, lane 0 for the header), so k_backup_select needs no
 // fence between its two halves: a lane's load follows its own store in program order.
-__device__ __forceinline__ void expand_backup_body(const AzParams &P, int tree, int lane, const float *d_value,
+__device__ __forceinline__ void expand_backup_body(const AzParams &P, int tree, int out, int lane, const float *d_value,
                                                    const float *d_prior, int prior_is_log)
 {
     constexpr int E = EPL;
@@ -1197,7 +1200,7 @@ __device__ __forceinline__ void expand_backup_body(const AzParams &P, int tree, 
 #pragma unroll
         for (int k = 0; k < E; k++) {
             const int a = lane * E + k;
-            pr[k] = a < SIZE ? d_prior[(size_t)tree * SIZE + a] : 0.f;
+            pr[k] = a < SIZE ? d_prior[(size_t)out * SIZE + a] : 0.f;
         }
         NodeRegs<E> nd;
         mix_prior<E>(P, pr, prior_is_log != 0, noise_row, lane, nd.p);
@@ -1224,7 +1227,7 @@ __device__ __forceinline__ void expand_backup_body(const AzParams &P, int tree, 
             if (P.noise != nullptr) T->noise_row = noise_row + 1;
             T->stats[1] += 1;
         }
-        value = -d_value[tree]; // cmcts.cpp:228
+        value = -d_value[out]; // cmcts.cpp:228
     } else {
         value = unif(T->leaf_value);
         if (lane == 0) T->stats[2] += 1;
@@ -1247,7 +1250,7 @@ __device__ __forceinline__ void expand_backup_body(const AzParams &P, int tree, 
 __global__ __launch_bounds__(64) void k_expand_backup(AzParams P, const float *d_value, const float *d_prior,
                                                        int prior_is_log)
 {
-    expand_backup_body(P, blockIdx.x, threadIdx.x, d_value, d_prior, prior_is_log);
+    expand_backup_body(P, blockIdx.x, blockIdx.x, threadIdx.x, d_value, d_prior, prior_is_log);
 }
 // The backup of one search step and the select of the next in one launch (the network search's inner
 // loop: one launch and one pass over the tree header less per step).
@@ -1255,8 +1258,59 @@ __global__ __launch_bounds__(64) void k_backup_select(AzParams P, const float *d
                                                        int prior_is_log, float *d_boards, int *d_leaf_kind,
                                                        unsigned *d_expand_mask, unsigned *d_clear_mask)
 {
-    expand_backup_body(P, blockIdx.x, threadIdx.x, d_value, d_prior, prior_is_log);
-    select_body(P, blockIdx.x, threadIdx.x, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
+    expand_backup_body(P, blockIdx.x, blockIdx.x, threadIdx.x, d_value, d_prior, prior_is_log);
+    select_body(P, blockIdx.x, blockIdx.x, threadIdx.x, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
+}
+
+// ------------------------------------------- network search in one launch (few trees)
+// Cmcts::simulate with the reference network (cmcts.cpp:83-282) for batches of at most one tree per CU:
+// ONE launch for all searches of a call instead of two launches per search, whose dispatch gaps are a
+// third of such a step.  A workgroup of eight wavefronts per tree: wavefront 0 runs select and expand +
+// backup (select_body / expand_backup_body, the code of the stepped kernels), all eight evaluate the leaf
+// (aznet::team_position, the code of k_net_eval); the leaf's planes, its code, the value and the log-priors
+// pass through LDS.  Same arithmetic as the launches it replaces, hence the same results.
+using NetG = aznet::Geo<S, 8>;
+constexpr int NET_SEARCH_LDS_FLOATS = 2 * NetG::BUF + 16 + NetG::SIZE + 2 * NetG::SIZE + NetG::SIZE + 16;
+__global__ __launch_bounds__(NetG::NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_search(
+    AzParams P, int th_num, int per, const float *prm, int front, int pol, int val)
+{
+    using G = NetG;
+    extern __shared__ float lds[];
+    float *F = lds, *W = lds + G::BUF;
+    float *red = lds + 2 * G::BUF;      // [16] reductions of the heads
+    float *logit = red + 16;            // [SIZE]
+    float *planes = logit + G::SIZE;    // [2][SIZE] the leaf as select writes it
+    float *logp = planes + 2 * G::SIZE; // [SIZE]
+    float *value = logp + G::SIZE;      // [1]
+    int *kind = reinterpret_cast<int *>(value + 1); // [2] the step's AZ_LEAF_* code, steps alternate between the cells
+    const int tree = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = uni(tid >> 6);
+    AzTree *T = &P.trees[tree];
+    if (uni(T->active) == 0 || uni(T->err) != 0) return; // (the whole workgroup: nothing to search)
+    for (int i = tid; i < 2 * G::BUF; i += G::NTHR) lds[i] = 0.f; // halos stay zero from here on
+    aznet::TeamCtx<G> ctx;
+    aznet::team_setup<G>(ctx, prm, front, pol, val, wave, lane);
+    __syncthreads();
+    int step = 0;
+    for (int w = 0; w < th_num; w++) {
+        // a new worker builds a new generator (cmcts.cpp:132-133): the noise stream restarts
+        if (tid == 0) T->noise_row = 0;
+        for (int i = 0; i < per; i++, step++) {
+            // (the code goes to the cell of this step's parity: a wavefront that has not read the step's code
+            // yet when wavefront 0 is already selecting for the next step finds it untouched; by the time the
+            // cell is written again every wavefront has passed the barrier of the step in between)
+            int *kd = kind + (step & 1);
+            if (wave == 0) select_body(P, tree, 0, lane, planes, kd, nullptr, nullptr);
+            __syncthreads();
+            if (kd[0] == AZ_LEAF_EXPAND) { // (workgroup-uniform)
+                aznet::team_position<G>(ctx, F, W, red, logit, planes, value, logp, tid, wave, lane);
+                __syncthreads();
+            }
+            if (wave == 0) expand_backup_body(P, tree, 0, lane, value, logp, 1);
+            // (wavefront 0 goes on to the next select; the others wait for it at the barrier above)
+        }
+    }
 }
 
 // first maximum of the root's visit counts, -1 for an idle tree or an unexpanded root
@@ -1700,6 +1754,20 @@ int l_backup_select(const AzParams &P, const float *d_value, const float *d_prio
                        d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
     return launch_status();
 }
+int l_net_search(const AzParams &P, int th_num, int per, const float *d_params, int front, int pol, int val, void *stream)
+{
+    const size_t lds_bytes = (size_t)NET_SEARCH_LDS_FLOATS * sizeof(float);
+    static bool configured[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !configured[dev]) {
+        if (hipFuncSetAttribute((const void *)k_net_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return 1;
+        if (dev >= 0 && dev < 64) configured[dev] = true;
+    }
+    hipLaunchKernelGGL(k_net_search, dim3(P.n_trees), dim3(NetG::NTHR), lds_bytes, (hipStream_t)stream, P, th_num, per, d_params,
+                       front, pol, val);
+    return launch_status();
+}
 int l_expand_backup(const AzParams &P, const float *d_value, const float *d_prior, int is_log, void *stream)
 {
     hipLaunchKernelGGL(k_expand_backup, dim3(P.n_trees), dim3(64), 0, (hipStream_t)stream, P, d_value, d_prior,
@@ -1755,7 +1823,7 @@ int l_dirichlet(double *d_table, int rows, double alpha, unsigned long long seed
 extern "C" const AzShapeOps *AZ_CAT(az_shape_ops_, AZ_S)(void)
 {
     static const AzShapeOps ops = {
-        AZ_S, SP, l_simulate_fused, l_select, l_expand_backup, l_backup_select, l_make_move, l_clear, l_select_greedy, l_get_counts,
+        AZ_S, SP, l_simulate_fused, l_select, l_expand_backup, l_backup_select, l_net_search, l_make_move, l_clear, l_select_greedy, l_get_counts,
         l_choose_moves, l_dirichlet, l_restart,
     };
     return &ops;

@@ -1724,6 +1724,8 @@ template <class G> int launch(const float *boards, const int *leaf_kind, int n, 
 // az_net_set_form says otherwise
 static std::atomic<int> g_net_form{getenv("AZ_NET_FORM") != nullptr ? atoi(getenv("AZ_NET_FORM")) : AZ_NET_FORM_AUTO};
 
+int az_net_get_form() { return g_net_form.load(std::memory_order_relaxed); }
+
 extern "C" {
 
 int az_net_set_form(int form)

@@ -89,18 +89,22 @@ def test_simulate_net_equals_the_three_step_path(S, threads):
     b.close()
 
 
+@pytest.mark.parametrize("one_launch", [False, True])
 @pytest.mark.parametrize("B,S,plies", [(77, 5, 24), (130, 7, 3), (33, 16, 3)])
-def test_simulate_net_position_mask_with_idle_and_terminal_leaves(B, S, plies):
+def test_simulate_net_position_mask_with_idle_and_terminal_leaves(B, S, plies, one_launch):
     """az_simulate_net tells its evaluator which positions to evaluate through the bit mask az_select
     fills (the three-step path scans the leaf codes): tree counts that are no multiple of 32, idle trees
-    and, on small boards, searches that end on finished games; every statistic stays bit-identical."""
+    and, on small boards, searches that end on finished games; every statistic stays bit-identical.
+    one_launch: the kernel form is left to the library, which then runs a batch this small as ONE launch
+    per call (a workgroup per tree selects, evaluates and backs up): the same comparison for that path."""
     import torch
     from alphazero_amd import engine as E
 
     sims, size = 40, S * S  # (5x5: the board fills up, searches end on finished games and the games themselves end)
     _, ev = _fused(S, seed=5)
     # the one-wavefront kernels are the ones that read the mask; batches this small would get the team kernel
-    assert ev.L.az_net_set_form(2 if S <= 15 else 4) == 0  # AZ_NET_FORM_WINOGRAD / AZ_NET_FORM_WIDE
+    if not one_launch:
+        assert ev.L.az_net_set_form(2 if S <= 15 else 4) == 0  # AZ_NET_FORM_WINOGRAD / AZ_NET_FORM_WIDE
     active = (np.arange(B) % 5 != 2).astype(np.uint8)
     engs = []
     for _ in range(2):

@@ -37,7 +37,8 @@ def main():
         n_fused += 1
         if n_fused % 8 == 0:
             B, S2 = int(rng.integers(2, 200)), int(rng.choice([5, 6, 7, 9, 13, 15, 16, 20]))
-            TC.test_simulate_net_position_mask_with_idle_and_terminal_leaves(B, S2, int(rng.integers(2, 6)) if S2 != 5 else 24)
+            TC.test_simulate_net_position_mask_with_idle_and_terminal_leaves(B, S2, int(rng.integers(2, 6)) if S2 != 5 else 24,
+                                                                             bool(rng.integers(0, 2)))
             n_net += 1
         print(f"\r{n_fused} fused, {n_net} network configurations ok", end="", flush=True)
     print()

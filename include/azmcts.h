@@ -166,7 +166,9 @@ int az_expand_backup(az_engine *e, const float *d_value, const float *d_prior, i
  * (the torch::jit module of cmcts.cpp:137,217): n searches on every active tree,
  * each search step = az_select, az_net_eval on the step's leaves, az_expand_backup,
  * all queued on `stream` by this one call (the loop of cmcts.cpp:151-154 without a
- * return to the caller per search; thread fan-out as in az_simulate_fused).
+ * return to the caller per search; thread fan-out as in az_simulate_fused).  An
+ * engine of at most one tree per CU runs the whole call as ONE launch (a workgroup
+ * per tree selects, evaluates and backs up; same arithmetic, same results).
  * d_params / *_layers: as az_net_eval takes them.  The step's leaf boards, codes,
  * values and log-priors live in a buffer the engine allocates on first use.
  * Asynchronous; errors surface at az_sync_check. */

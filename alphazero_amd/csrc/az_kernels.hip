@@ -1160,7 +1160,16 @@ __device__ __forceinline__ void select_body(const AzParams &P, int tree, int out
         if (d_expand_mask != nullptr && kind == AZ_LEAF_EXPAND) atomicOr(&d_expand_mask[(out >> 5) * AZ_MASK_STRIDE], 1u << (out & 31));
     }
 }
-__global__ __launch_bounds__(64) void k_select(AzParams P, float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask,
+// Register budget of the step kernels.  Boards up to 16x16 (four actions per lane): eight wavefronts per SIMD,
+// i.e. 64 registers, so that 8192 trees are resident at once instead of in two rounds of seven per SIMD (no
+// spill; 8 us less per search step at 8192 trees).  With eight actions per lane 64 registers would spill.
+// (-DAZ_STEP_NO_OCC builds them without the bound, for A/B timing.)
+#ifdef AZ_STEP_NO_OCC
+#define AZ_STEP_OCC
+#else
+#define AZ_STEP_OCC __attribute__((amdgpu_waves_per_eu(EPL <= 4 ? 8 : 1, 8)))
+#endif
+__global__ __launch_bounds__(64) AZ_STEP_OCC void k_select(AzParams P, float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask,
                                                unsigned *d_clear_mask)
 {
     select_body(P, blockIdx.x, blockIdx.x, threadIdx.x, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
@@ -1254,7 +1263,7 @@ __global__ __launch_bounds__(64) void k_expand_backup(AzParams P, const float *d
 }
 // The backup of one search step and the select of the next in one launch (the network search's inner
 // loop: one launch and one pass over the tree header less per step).
-__global__ __launch_bounds__(64) void k_backup_select(AzParams P, const float *d_value, const float *d_prior,
+__global__ __launch_bounds__(64) AZ_STEP_OCC void k_backup_select(AzParams P, const float *d_value, const float *d_prior,
                                                        int prior_is_log, float *d_boards, int *d_leaf_kind,
                                                        unsigned *d_expand_mask, unsigned *d_clear_mask)
 {

@@ -1167,7 +1167,10 @@ __device__ __forceinline__ void select_body(const AzParams &P, int tree, int out
 #ifdef AZ_STEP_NO_OCC
 #define AZ_STEP_OCC
 #else
-#define AZ_STEP_OCC __attribute__((amdgpu_waves_per_eu(EPL <= 4 ? 8 : 1, 8)))
+#ifndef AZ_STEP_OCC_WIDE
+#define AZ_STEP_OCC_WIDE 1 /* (experiments: the bound for boards with eight actions per lane) */
+#endif
+#define AZ_STEP_OCC __attribute__((amdgpu_waves_per_eu(EPL <= 4 ? 8 : AZ_STEP_OCC_WIDE, 8)))
 #endif
 __global__ __launch_bounds__(64) AZ_STEP_OCC void k_select(AzParams P, float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask,
                                                unsigned *d_clear_mask)

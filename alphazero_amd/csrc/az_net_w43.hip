@@ -1,0 +1,384 @@
+// Batched policy/value network evaluation (the reference's `simplerNN`, src/model.py:9-44, inference mode),
+// Winograd F(4x4, 3x3) form of the 3x3 layers for boards of 15x15 and 16x16: see az_net.hip for the other forms
+// and for what is common to all of them (activations of a position resident in LDS, plane-major with a zero halo,
+// every layer in place, f32 matrix instructions v_mfma_f32_16x16x4_f32).
+//
+// A 4x4 tile of outputs comes from the 6x6 input patch around it through 36 element-wise products in a
+// transformed domain instead of 9 multiply-adds per output: 36 products per 16 outputs against 64 in the
+// F(2x2,3x3) form and 144 in the direct form.  A board of 15x15 or 16x16 is a 4x4 grid of such tiles, i.e.
+// exactly the 16 rows of the M side of one matrix instruction, so a 16 -> 16 channel layer is 36 (transformed
+// positions) x 4 (K steps of four input channels) = 144 matrix instructions against 256 and 504.
+//   One wavefront per position, two wavefronts per SIMD (eight positions per CU, no barrier anywhere): a
+//   wavefront alone on a SIMD issues a vector instruction only every 5 - 8 cycles and its vector instructions
+//   do not overlap with its own matrix instructions, two wavefronts fill each other's gaps.  256 registers per
+//   wavefront then: the 36 accumulators of four registers (144, AGPRs) leave 112, so everything else streams.
+//   Lane (m, kq) of K step ks loads the 6x6 patch of tile m (tile row m >> 2, tile column m & 3) of channel
+//   4*ks + kq and forms V = Bt d B in two halves: the column transforms of the whole patch (t = Bt d, 72
+//   operations, in the registers of the patch), then ROW BY ROW the row transform (12 operations) whose six
+//   results are the A operands of the six matrix instructions issued right behind it; the registers of a row
+//   of t then take the same row of the next K step's patch.  The B operands are the host-transformed weights
+//   U = G g Gt with the batch-norm scale folded in, streamed from memory through a ring of 12 registers, two
+//   rows ahead of their use and across layer ends (all wavefronts read the same 36 KB per layer: cache hits).
+//   After the last K step lane (co, kq) holds, for the four tiles of tile row kq and its output channel co, the
+//   36 transformed sums; Y = At M A gives the 4x4 outputs.  The batch-norm shift enters through the initial
+//   value of the one accumulator (transformed position (1, 1)) that feeds every output with weight one.
+// Patches of the last tile row / column reach past the halo: at 15x15 that is the next row's left halo cell, the
+// next plane's top halo or the zero tail behind the last plane; at 16x16 they end on the halo exactly.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <utility>
+
+#include "../../include/azmcts.h"
+#include "az_common.h"
+
+#include "az_net_team.h"
+#include "az_net_parts.h"
+
+namespace {
+using namespace aznet;
+
+template <int S> struct W43Geo {
+    using G = Geo<S>;
+    static_assert(S == 15 || S == 16, "a 4x4 grid of tiles whose patches end on zero cells");
+    static constexpr int LDS_BYTES = (G::BUF + 64) * 4; // + the zero tail behind the last plane
+    static constexpr int WGS0 = (160 * 1024 - 2048) / (LDS_BYTES + 256); // positions per CU: eight at 15x15, seven at 16x16
+    static constexpr int WGS = WGS0 > 8 ? 8 : WGS0;
+};
+
+// one-dimensional input transform Bt d of F(4, 3)
+__device__ __forceinline__ void w43_bt(float d0, float d1, float d2, float d3, float d4, float d5, float &t0, float &t1, float &t2,
+                                       float &t3, float &t4, float &t5)
+{
+    const float p = fmaf(-4.f, d2, d4), q = fmaf(-4.f, d1, d3), c = d4 - d2, e = d3 - d1;
+    t0 = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+    t1 = p + q;
+    t2 = p - q;
+    t3 = fmaf(2.f, e, c);
+    t4 = fmaf(-2.f, e, c);
+    t5 = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+}
+// one-dimensional output transform At m of F(4, 3)
+__device__ __forceinline__ void w43_at(float m0, float m1, float m2, float m3, float m4, float m5, float &y0, float &y1, float &y2,
+                                       float &y3)
+{
+    const float p = m1 + m2, q = m1 - m2, r = m3 + m4, s = m3 - m4;
+    y0 = (m0 + p) + r;
+    y1 = fmaf(2.f, s, q);
+    y2 = fmaf(4.f, r, p);
+    y3 = fmaf(8.f, s, q) + m5;
+}
+
+// Stores (wr), adds up (sum) or parks (keep) the 4x4 outputs y[a][b] of the lane's r-th tile (tile row kq, tile
+// column r), ReLU applied here.  Cells outside a 15x15 board are halo cells: the column is skipped, the row
+// receives zero.  cob = co*PS + (4*kq + 1)*ROW + 1.
+template <int S, bool wr, bool keep, bool sum, int R>
+__device__ __forceinline__ void w43_emit(float *buf, int cob, int kq, float (&y)[4][4], float *fc, int fz, float &lsum)
+{
+    using G = Geo<S>;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const bool col_ok = 4 * R + b < S; // (a constant)
+            float v = __builtin_amdgcn_fmed3f(y[a][b], 0.f, INFINITY);
+            if (!col_ok) v = 0.f;
+            if (S == 15 && a == 3 && col_ok) v = kq == 3 ? 0.f : v;
+            if constexpr (wr) {
+                if (col_ok) buf[cob + a * G::ROW + 4 * R + b] = v;
+            }
+            if constexpr (sum) lsum += v;
+            if constexpr (keep) fc[fz + (a * 4 + b) * 4 + R] = v;
+        }
+}
+
+// the trunk output back from its private copy
+template <int S> __device__ __forceinline__ void w43_restore(float *buf, int lane, const float *fc, int fz)
+{
+    using G = Geo<S>;
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    const int cob = (l & 15) * G::PS + (4 * (l >> 4) + 1) * G::ROW + 1;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (4 * r + b < S) buf[cob + a * G::ROW + 4 * r + b] = fc[fz + (a * 4 + b) * 4 + r];
+}
+
+constexpr int W43_RING = 12; // weight registers in flight: two rows of six matrix instructions
+
+// One 3x3 layer.  KS = K steps: 4 for 16 input channels, 1 for the two input planes (K indices 2..3 carry zero
+// weights and read planes 0..1 again).  `layer`: the layer's weights [KS][36][64] in the order the matrix
+// instructions take them; w[] holds the first W43_RING of them on entry and the first W43_RING of `nextp` (the
+// layer that runs next) on return.
+template <int S, int KS, bool wr, bool keep, bool sum>
+__device__ __forceinline__ void w43_layer(float *buf, float (&w)[W43_RING], const float *layer, const float *nextp, float sh, int lane,
+                                          float *fc, int fz, float &lsum)
+{
+    using G = Geo<S>;
+    int l = lane;
+    asm volatile("" : "+v"(l)); // (addresses are formed per layer instead of living in registers across the position loop)
+    const int kq = l >> 4, co = l & 15;
+    const int kqp = KS == 4 ? kq : (kq & 1); // plane of this lane's K index in K step 0
+    unsigned wo = (unsigned)l * 4u;          // (uniform base + 32-bit byte offset: one offset register for all weight loads)
+    asm("" : "+v"(wo));
+    int po = kqp * G::PS + 4 * (co >> 2) * G::ROW + 4 * (co & 3);
+    asm("" : "+v"(po)); // one address for all patches; channels and cells are immediate offsets
+    const float *p0 = buf + po;
+    float t[36];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) t[i * 6 + j] = p0[i * G::ROW + j];
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+        w43_bt(t[j], t[6 + j], t[12 + j], t[18 + j], t[24 + j], t[30 + j], t[j], t[6 + j], t[12 + j], t[18 + j], t[24 + j], t[30 + j]);
+    const f32x4 shv = (f32x4){sh, sh, sh, sh}, zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[36];
+    static_for<KS * 6>([&](auto rr) {
+        constexpr int R = decltype(rr)::value, ks = R / 6, i = R % 6;
+        __builtin_amdgcn_sched_barrier(0);
+        float a6[6];
+        w43_bt(t[i * 6], t[i * 6 + 1], t[i * 6 + 2], t[i * 6 + 3], t[i * 6 + 4], t[i * 6 + 5], a6[0], a6[1], a6[2], a6[3], a6[4], a6[5]);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const int x = i * 6 + j, g = R * 6 + j;
+            if (ks == 0) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a6[j], w[g % W43_RING], x == 7 ? shv : zero, 0, 0, 0);
+            else acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a6[j], w[g % W43_RING], acc[x], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 6; j++) { // the ring: the weights of the row after the next
+            const int g = R * 6 + j + W43_RING;
+            const float *src = g < KS * 36 ? layer + g * 64 : nextp + (g - KS * 36) * 64;
+            w[g % W43_RING] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(src) + wo);
+        }
+        if constexpr (ks + 1 < KS) { // the same row of the next K step's patch; its column transforms once the patch is complete
+            const float *p = p0 + (ks + 1) * 4 * G::PS + i * G::ROW;
+#pragma unroll
+            for (int j = 0; j < 6; j++) t[i * 6 + j] = p[j];
+            if constexpr (i == 5) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 6; j++)
+                    w43_bt(t[j], t[6 + j], t[12 + j], t[18 + j], t[24 + j], t[30 + j], t[j], t[6 + j], t[12 + j], t[18 + j], t[24 + j],
+                           t[30 + j]);
+            }
+        }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    const int cob = co * G::PS + (4 * kq + 1) * G::ROW + 1;
+    static_for<4>([&](auto rr) {
+        constexpr int r = decltype(rr)::value;
+        float s[4][6], y[4][4];
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+            w43_at(acc[j][r], acc[6 + j][r], acc[12 + j][r], acc[18 + j][r], acc[24 + j][r], acc[30 + j][r], s[0][j], s[1][j], s[2][j],
+                   s[3][j]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) w43_at(s[q][0], s[q][1], s[q][2], s[q][3], s[q][4], s[q][5], y[q][0], y[q][1], y[q][2], y[q][3]);
+        w43_emit<S, wr, keep, sum, r>(buf, cob, kq, y, fc, fz, lsum);
+    });
+}
+
+template <int S>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_w43(
+    const float *boards, const int *leaf_kind, const unsigned *expand_mask, int n, const float *prm, int front, int pol, int val,
+    float *value_out, float *logp_out)
+{
+    using G = Geo<S>;
+    extern __shared__ float lds[];
+    float *buf = lds;
+    int *todo = reinterpret_cast<int *>(lds + G::BUF + 64); // [ceil(n / gridDim.x)] positions of this workgroup
+    const int lane = threadIdx.x;
+    const int co = lane & 15, kq = lane >> 4;
+    for (int i = lane; i < G::BUF + 64; i += 64) buf[i] = 0.f; // halos (and the tail) stay zero from here on
+    const int nl = front - 1 + pol + val;
+    const float *p_policy = prm + FIRST_FLOATS + (size_t)nl * LAYER_FLOATS;
+    const float *p_value = p_policy + POLICY_FLOATS;
+    const float *p_w43 = p_value + VALUE_FLOATS + (size_t)nl * WINO_FLOATS + WINO_FIRST_FLOATS;
+    // execution order: trunk, value branch, policy branch (parameter order: trunk, policy, value)
+    auto layer_params = [&](int e) {
+        const int idx = e < front - 1 ? e : (e < front - 1 + val ? e + pol : e - val);
+        return p_w43 + (size_t)idx * W43_FLOATS;
+    };
+    const float *p_first = p_w43 + (size_t)nl * W43_FLOATS;
+    float wpb[4]; // policy head as a B operand: B[k = ci][n = tap]
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) wpb[ks] = co < 9 ? p_policy[co * CH + ks * 4 + kq] : 0.f;
+    const float p_bias = p_policy[9 * CH];
+    const float wv = p_value[co], v_bias = p_value[CH];
+
+    int n_mine;
+    const bool listed = expand_mask != nullptr || leaf_kind != nullptr; // positions come from todo[]
+    if (expand_mask != nullptr) {
+        n_mine = list_positions_mask(expand_mask, n, todo, lane);
+    } else if (leaf_kind != nullptr) {
+        n_mine = list_positions<64>(leaf_kind, n, todo, nullptr, lane);
+    } else {
+        n_mine = n > (int)blockIdx.x ? (n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    }
+    __syncthreads(); // (a single wavefront: orders the LDS traffic)
+
+#ifdef AZ_NET_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_0 = __builtin_readcyclecounter();
+#define NST(i) do { unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_t; st_t = t_; } while (0)
+#else
+#define NST(i) do { } while (0)
+#endif
+    // The trunk output, which both branches start from, is parked in private memory while the value branch owns the
+    // buffer; indexed through a value the compiler cannot see through, so that the array really lives in memory.
+    float fc[64];
+    int fz;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(fz));
+    constexpr int PPL = (G::SIZE + 63) / 64; // pixels this lane loads, gathers and stores: lane, lane + 64, ...
+    float in0[PPL], in1[PPL];                // the next position's input planes, requested one position ahead
+    auto request_board = [&](int pos) {
+        const float *bp = boards + (size_t)pos * CIN * G::SIZE;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) {
+            const int p = lane + 64 * i;
+            in0[i] = p < G::SIZE ? bp[p] : 0.f;
+            in1[i] = p < G::SIZE ? bp[G::SIZE + p] : 0.f;
+        }
+    };
+    if (n_mine > 0) request_board(listed ? todo[0] : (int)blockIdx.x);
+    const float *first16 = nl > 0 ? layer_params(0) : p_first; // the layer behind the input layer
+    float w[W43_RING]; // the weight ring: starts with the input layer's first rows, every layer refills it for the next
+#pragma unroll
+    for (int g = 0; g < W43_RING; g++) w[g] = p_first[g * 64 + lane];
+    const float u0sh = p_first[36 * 64 + co];
+    float ush = nl > 0 ? layer_params(0)[4 * 36 * 64 + co] : 0.f;
+    for (int it = 0; it < n_mine; it++) {
+        const int pos = listed ? todo[it] : (int)blockIdx.x + it * (int)gridDim.x;
+#ifdef AZ_NET_STAMPS
+        st_t = __builtin_readcyclecounter();
+#endif
+#pragma unroll
+        for (int i = 0; i < PPL; i++) { // the two input planes (requested while the previous position was in its heads)
+            const int p = lane + 64 * i;
+            if (p < G::SIZE) {
+                const int ctr = pix_index<S>(p);
+                buf[ctr] = in0[i];
+                buf[G::PS + ctr] = in1[i];
+            }
+        }
+        __syncthreads();
+        NST(0);
+        float vsum = 0.f, lsum = 0.f;
+        // input layer; it is also the trunk's last layer when front == 1
+        if (front > 1) w43_layer<S, 1, true, false, false>(buf, w, p_first, first16, u0sh, lane, fc, fz, lsum);
+        else if (val > 0) w43_layer<S, 1, true, true, false>(buf, w, p_first, first16, u0sh, lane, fc, fz, lsum);
+        else w43_layer<S, 1, true, false, true>(buf, w, p_first, first16, u0sh, lane, fc, fz, lsum);
+        if (front == 1 && val == 0) vsum = lsum;
+        __syncthreads();
+        NST(6);
+        for (int e = 0; e < nl; e++) {
+            const bool last_trunk = e == front - 2;
+            const bool last_value = val > 0 && e == front - 1 + val - 1;
+            const bool first_policy = pol > 0 && e == front - 1 + val;
+            const float *layer = layer_params(e);
+            const float *nextp = e + 1 < nl ? layer_params(e + 1) : p_first; // (the last layer fetches the next position's first)
+            if (first_policy && val > 0) { // the trunk output comes back
+                w43_restore<S>(buf, lane, fc, fz);
+                __syncthreads();
+            }
+            const float sh = ush;
+            ush = layer_params(e + 1 < nl ? e + 1 : 0)[4 * 36 * 64 + co]; // (requested a layer ahead: its latency runs under this layer)
+            lsum = 0.f;
+            NST(4);
+            if (last_value) w43_layer<S, 4, false, false, true>(buf, w, layer, nextp, sh, lane, fc, fz, lsum);
+            else if (last_trunk && val > 0) w43_layer<S, 4, true, true, false>(buf, w, layer, nextp, sh, lane, fc, fz, lsum);
+            else if (last_trunk) w43_layer<S, 4, true, false, true>(buf, w, layer, nextp, sh, lane, fc, fz, lsum);
+            else w43_layer<S, 4, true, false, false>(buf, w, layer, nextp, sh, lane, fc, fz, lsum);
+            if (last_value || (last_trunk && val == 0)) vsum = lsum;
+            __syncthreads();
+            NST(1);
+        }
+        // policy head input: the policy branch's output, or the trunk output when there is no such branch
+        if (pol == 0 && val > 0) {
+            w43_restore<S>(buf, lane, fc, fz);
+            __syncthreads();
+        }
+        // ---- value head: board average of the 1x1 convolution + bias, tanh
+        const float vpart = wave_reduce<false>(wv * vsum);
+        if (lane == 0) value_out[pos] = tanhf(vpart / (float)G::SIZE + v_bias);
+        if (it + 1 < n_mine) request_board(listed ? todo[it + 1] : (int)blockIdx.x + (it + 1) * (int)gridDim.x);
+        // ---- policy head: per-tap partial planes on the matrix cores, written over the input
+        policy_taps_wide<S>(buf, wpb, lane);
+        __syncthreads();
+        // gather of the nine planes + bias, log-softmax over the board
+        float logit[PPL];
+        float lmax = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) {
+            const int p = lane + 64 * i;
+            const int ctr = pix_index<S>(p < G::SIZE ? p : 0);
+            float s = p_bias;
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) s += buf[tap * G::PS + ctr + (tap / 3 - 1) * G::ROW + (tap % 3 - 1)];
+            logit[i] = p < G::SIZE ? s : -INFINITY;
+            lmax = fmaxf(lmax, logit[i]);
+        }
+        lmax = wave_reduce<true>(lmax);
+        float esum = 0.f;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) esum += lane + 64 * i < G::SIZE ? expf(logit[i] - lmax) : 0.f;
+        esum = wave_reduce<false>(esum);
+        const float lse = lmax + logf(esum);
+#pragma unroll
+        for (int i = 0; i < PPL; i++)
+            if (lane + 64 * i < G::SIZE) logp_out[(size_t)pos * G::SIZE + lane + 64 * i] = logit[i] - lse;
+        __syncthreads(); // the gather is over before the next position's input lands in the buffer
+        NST(3);
+        // planes 2..15 keep leftovers (partial planes, old activations): the input layer reads planes 0..1 only
+    }
+#ifdef AZ_NET_STAMPS
+    if (lane == 0 && n_mine > 0 && leaf_kind == nullptr) { // diagnostic build: cycle sums over the log-priors of the first position
+        st_acc[5] = __builtin_readcyclecounter() - st_0;
+        st_acc[7] = (unsigned long long)n_mine;
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(logp_out + (size_t)blockIdx.x * G::SIZE);
+        for (int q = 0; q < 8; q++) o[q] = st_acc[q];
+    }
+#endif
+}
+
+template <int S> int launch_w43(const float *boards, const int *leaf_kind, const unsigned *expand_mask, int n, const float *prm,
+                                int front, int pol, int val, float *value_out, float *logp_out, hipStream_t st)
+{
+    using W = W43Geo<S>;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int grid = cus * W::WGS;
+    if (grid > n) grid = n;
+    const size_t lds_bytes = (size_t)W::LDS_BYTES + (size_t)((n + grid - 1) / grid) * sizeof(int);
+    static size_t configured[64] = {}; // largest size the kernel has been opened up to, per device
+    if (dev < 0 || dev >= 64 || lds_bytes > configured[dev]) {
+        if (hipFuncSetAttribute((const void *)k_net_w43<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return AZ_ERR_HIP;
+        if (dev >= 0 && dev < 64) configured[dev] = lds_bytes;
+    }
+    hipLaunchKernelGGL(k_net_w43<S>, dim3(grid), dim3(64), lds_bytes, st, boards, leaf_kind, expand_mask, n, prm, front, pol, val,
+                       value_out, logp_out);
+    return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
+}
+
+} // namespace
+
+// Launches the F(4x4,3x3) kernel; AZ_ERR_ARG for a board size it is not built for.  Arguments as az_net_eval_masked.
+int az_net_w43_launch(int shape, int n, const float *d_boards, const int *d_leaf_kind, const unsigned *d_expand_mask,
+                      const float *d_params, int front_layers, int policy_layers, int value_layers, float *d_value, float *d_logp,
+                      hipStream_t st)
+{
+    switch (shape) {
+    case 15:
+        return launch_w43<15>(d_boards, d_leaf_kind, d_expand_mask, n, d_params, front_layers, policy_layers, value_layers, d_value,
+                              d_logp, st);
+    case 16:
+        return launch_w43<16>(d_boards, d_leaf_kind, d_expand_mask, n, d_params, front_layers, policy_layers, value_layers, d_value,
+                              d_logp, st);
+    default: return AZ_ERR_ARG;
+    }
+}

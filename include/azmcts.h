@@ -327,8 +327,11 @@ int az_net_param_floats(int front_layers, int policy_layers, int value_layers);
  * of the 3x3 layers for every size (one wavefront per position up to 15x15, a team of
  * four above; DIRECT above 15x15 is the same as TEAM); TEAM = the direct-form team kernel
  * for every size; WIDE = the one-wavefront-per-SIMD Winograd kernel from 12x12 on (AUTO's
- * choice below that).  Process-wide; initial value from the environment (AZ_NET_FORM). */
-enum { AZ_NET_FORM_AUTO = 0, AZ_NET_FORM_DIRECT = 1, AZ_NET_FORM_WINOGRAD = 2, AZ_NET_FORM_TEAM = 3, AZ_NET_FORM_WIDE = 4 };
+ * choice below that); W43 = the Winograd F(4x4,3x3) kernel with one wavefront per SIMD at 15x15
+ * and 16x16 (AUTO's choice at the other sizes).  Process-wide; initial value from the environment
+ * (AZ_NET_FORM). */
+enum { AZ_NET_FORM_AUTO = 0, AZ_NET_FORM_DIRECT = 1, AZ_NET_FORM_WINOGRAD = 2, AZ_NET_FORM_TEAM = 3, AZ_NET_FORM_WIDE = 4,
+       AZ_NET_FORM_W43 = 5 };
 int az_net_set_form(int form);
 int az_net_eval(int shape, int n, const float *d_boards, const int *d_leaf_kind, const float *d_params,
                 int front_layers, int policy_layers, int value_layers, float *d_value, float *d_logp, void *stream);

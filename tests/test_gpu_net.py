@@ -34,7 +34,7 @@ def _boards(n, shape, seed):
     return b.reshape(n, 2, shape, shape)
 
 
-FORMS = {"auto": 0, "direct": 1, "winograd": 2, "team": 3, "wide": 4}  # AZ_NET_FORM_* of include/azmcts.h
+FORMS = {"auto": 0, "direct": 1, "winograd": 2, "team": 3, "wide": 4, "w43": 5}  # AZ_NET_FORM_* of include/azmcts.h
 
 
 @pytest.fixture
@@ -51,7 +51,7 @@ def net_form():
     lib.az_net_set_form(FORMS["auto"])
 
 
-@pytest.mark.parametrize("form", ["auto", "direct", "winograd", "team", "wide"])
+@pytest.mark.parametrize("form", ["auto", "direct", "winograd", "team", "wide", "w43"])
 @pytest.mark.parametrize("shape,front,pol,val,n", [(15, 4, 2, 2, 300), (13, 4, 2, 2, 50), (20, 3, 1, 2, 40),
                                                      (7, 1, 0, 0, 9), (5, 2, 3, 1, 1100), (14, 2, 0, 1, 70),
                                                      (12, 1, 1, 0, 33), (10, 3, 1, 1, 20), (6, 2, 1, 1, 5),
@@ -67,6 +67,8 @@ def test_fused_net_matches_torch_float64(shape, front, pol, val, n, form, net_fo
 
     if shape > 15 and form == "direct":
         pytest.skip("above 15x15 the direct form is the team kernel")
+    if form == "w43" and shape not in (15, 16):
+        pytest.skip("the F(4x4,3x3) kernel is built for 15x15 and 16x16")
     m = _model(shape, front, pol, val, 3)
     boards = _boards(n, shape, 5)
     with torch.no_grad():

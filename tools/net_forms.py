@@ -31,7 +31,7 @@ def main():
     from alphazero_amd.evaluator import FusedNetEvaluator
     from alphazero_amd.model import PolicyValueNet
 
-    names = {0: "auto", 1: "direct", 2: "winograd", 3: "team", 4: "wide"}
+    names = {0: "auto", 1: "direct", 2: "winograd", 3: "team", 4: "wide", 5: "w43"}
     for s in [int(x) for x in args.shapes.split(",")]:
         torch.manual_seed(0)
         ev = FusedNetEvaluator(PolicyValueNet(s).eval(), s)

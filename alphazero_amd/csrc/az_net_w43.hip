@@ -46,34 +46,43 @@ template <int S> struct W43Geo {
     static constexpr int WGS = WGS0 > 8 ? 8 : WGS0;
 };
 
-// one-dimensional input transform Bt d of F(4, 3)
-__device__ __forceinline__ void w43_bt(float d0, float d1, float d2, float d3, float d4, float d5, float &t0, float &t1, float &t2,
-                                       float &t3, float &t4, float &t5)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <class T> __device__ __forceinline__ T w43_splat(float v);
+template <> __device__ __forceinline__ float w43_splat<float>(float v) { return v; }
+template <> __device__ __forceinline__ f32x2 w43_splat<f32x2>(float v) { return (f32x2){v, v}; }
+__device__ __forceinline__ float w43_fma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ f32x2 w43_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// one-dimensional input transform Bt d of F(4, 3); T = float, or two transforms side by side (packed instructions)
+template <class T> __device__ __forceinline__ void w43_bt(T d0, T d1, T d2, T d3, T d4, T d5, T &t0, T &t1, T &t2, T &t3, T &t4, T &t5)
 {
-    const float p = fmaf(-4.f, d2, d4), q = fmaf(-4.f, d1, d3), c = d4 - d2, e = d3 - d1;
-    t0 = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+    const T k4 = w43_splat<T>(4.f), m4 = w43_splat<T>(-4.f), m5 = w43_splat<T>(-5.f), k2 = w43_splat<T>(2.f), m2 = w43_splat<T>(-2.f);
+    const T p = w43_fma(m4, d2, d4), q = w43_fma(m4, d1, d3), c = d4 - d2, e = d3 - d1;
+    t0 = w43_fma(k4, d0, w43_fma(m5, d2, d4));
     t1 = p + q;
     t2 = p - q;
-    t3 = fmaf(2.f, e, c);
-    t4 = fmaf(-2.f, e, c);
-    t5 = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+    t3 = w43_fma(k2, e, c);
+    t4 = w43_fma(m2, e, c);
+    t5 = w43_fma(k4, d1, w43_fma(m5, d3, d5));
 }
 // one-dimensional output transform At m of F(4, 3)
-__device__ __forceinline__ void w43_at(float m0, float m1, float m2, float m3, float m4, float m5, float &y0, float &y1, float &y2,
-                                       float &y3)
+template <class T> __device__ __forceinline__ void w43_at(T m0, T m1, T m2, T m3, T m4, T m5, T &y0, T &y1, T &y2, T &y3)
 {
-    const float p = m1 + m2, q = m1 - m2, r = m3 + m4, s = m3 - m4;
+    const T k2 = w43_splat<T>(2.f), k4 = w43_splat<T>(4.f), k8 = w43_splat<T>(8.f);
+    const T p = m1 + m2, q = m1 - m2, r = m3 + m4, s = m3 - m4;
     y0 = (m0 + p) + r;
-    y1 = fmaf(2.f, s, q);
-    y2 = fmaf(4.f, r, p);
-    y3 = fmaf(8.f, s, q) + m5;
+    y1 = w43_fma(k2, s, q);
+    y2 = w43_fma(k4, r, p);
+    y3 = w43_fma(k8, s, q) + m5;
 }
 
-// Stores (wr), adds up (sum) or parks (keep) the 4x4 outputs y[a][b] of the lane's r-th tile (tile row kq, tile
-// column r), ReLU applied here.  Cells outside a 15x15 board are halo cells: the column is skipped, the row
-// receives zero.  cob = co*PS + (4*kq + 1)*ROW + 1.
-template <int S, bool wr, bool keep, bool sum, int R>
-__device__ __forceinline__ void w43_emit(float *buf, int cob, int kq, float (&y)[4][4], float *fc, int fz, float &lsum)
+// Stores (wr), adds up (sum) or parks (keep) the 4x4 outputs y[a][b] of the lane's R-th tile (tile row kq, tile
+// column R), ReLU applied here.  Cells outside a 15x15 board are halo cells: the column is skipped, the row
+// receives zero.  cob = co*PS + (4*kq + 1)*ROW + 1.  The flags are wave-uniform run-time values: one instance of
+// the layer serves the whole network (the kernel's code has to stay well inside the instruction cache).
+template <int S, int R>
+__device__ __forceinline__ void w43_emit(float *buf, int cob, int kq, float (&y)[4][4], bool wr, bool keep, bool sum, float *fc, int fz,
+                                         float &lsum)
 {
     using G = Geo<S>;
 #pragma unroll
@@ -84,12 +93,25 @@ __device__ __forceinline__ void w43_emit(float *buf, int cob, int kq, float (&y)
             float v = __builtin_amdgcn_fmed3f(y[a][b], 0.f, INFINITY);
             if (!col_ok) v = 0.f;
             if (S == 15 && a == 3 && col_ok) v = kq == 3 ? 0.f : v;
-            if constexpr (wr) {
-                if (col_ok) buf[cob + a * G::ROW + 4 * R + b] = v;
-            }
-            if constexpr (sum) lsum += v;
-            if constexpr (keep) fc[fz + (a * 4 + b) * 4 + R] = v;
+            y[a][b] = v;
         }
+    if (wr) {
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (4 * R + b < S) buf[cob + a * G::ROW + 4 * R + b] = y[a][b];
+    }
+    if (sum) {
+#pragma unroll
+        for (int a = 0; a < 4; a++) lsum += (y[a][0] + y[a][1]) + (y[a][2] + y[a][3]);
+    }
+    if (keep) {
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) fc[fz + (a * 4 + b) * 4 + R] = y[a][b];
+    }
 }
 
 // the trunk output back from its private copy
@@ -108,78 +130,134 @@ template <int S> __device__ __forceinline__ void w43_restore(float *buf, int lan
                 if (4 * r + b < S) buf[cob + a * G::ROW + 4 * r + b] = fc[fz + (a * 4 + b) * 4 + r];
 }
 
+#ifndef AZ_W43_PK_IN
+#define AZ_W43_PK_IN 1
+#endif
+#ifndef AZ_W43_PRIO_ROWS
+#define AZ_W43_PRIO_ROWS 0
+#endif
+#ifndef AZ_W43_PRIO_OUT
+#define AZ_W43_PRIO_OUT 3
+#endif
 constexpr int W43_RING = 12; // weight registers in flight: two rows of six matrix instructions
+static_assert(36 % W43_RING == 0, "every K step starts at ring slot 0");
 
-// One 3x3 layer.  KS = K steps: 4 for 16 input channels, 1 for the two input planes (K indices 2..3 carry zero
-// weights and read planes 0..1 again).  `layer`: the layer's weights [KS][36][64] in the order the matrix
-// instructions take them; w[] holds the first W43_RING of them on entry and the first W43_RING of `nextp` (the
-// layer that runs next) on return.
-template <int S, int KS, bool wr, bool keep, bool sum>
-__device__ __forceinline__ void w43_layer(float *buf, float (&w)[W43_RING], const float *layer, const float *nextp, float sh, int lane,
-                                          float *fc, int fz, float &lsum)
+// t = Bt d in place: the six column transforms of a patch, two columns side by side (packed instructions)
+__device__ __forceinline__ void w43_columns(float (&t)[36])
 {
-    using G = Geo<S>;
-    int l = lane;
-    asm volatile("" : "+v"(l)); // (addresses are formed per layer instead of living in registers across the position loop)
-    const int kq = l >> 4, co = l & 15;
-    const int kqp = KS == 4 ? kq : (kq & 1); // plane of this lane's K index in K step 0
-    unsigned wo = (unsigned)l * 4u;          // (uniform base + 32-bit byte offset: one offset register for all weight loads)
-    asm("" : "+v"(wo));
-    int po = kqp * G::PS + 4 * (co >> 2) * G::ROW + 4 * (co & 3);
-    asm("" : "+v"(po)); // one address for all patches; channels and cells are immediate offsets
-    const float *p0 = buf + po;
-    float t[36];
+#if AZ_W43_PK_IN
 #pragma unroll
-    for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j += 2) {
+        f32x2 c[6], o[6];
 #pragma unroll
-        for (int j = 0; j < 6; j++) t[i * 6 + j] = p0[i * G::ROW + j];
+        for (int i = 0; i < 6; i++) c[i] = (f32x2){t[i * 6 + j], t[i * 6 + j + 1]};
+        w43_bt(c[0], c[1], c[2], c[3], c[4], c[5], o[0], o[1], o[2], o[3], o[4], o[5]);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            t[i * 6 + j] = o[i][0];
+            t[i * 6 + j + 1] = o[i][1];
+        }
+    }
+#else
 #pragma unroll
     for (int j = 0; j < 6; j++)
         w43_bt(t[j], t[6 + j], t[12 + j], t[18 + j], t[24 + j], t[30 + j], t[j], t[6 + j], t[12 + j], t[18 + j], t[24 + j], t[30 + j]);
+#endif
+}
+
+// One K step: row by row the row transform of t (six A operands), six matrix instructions, the six weights of the
+// row after the next into the ring slots just used, and (more) the same row of the next K step's patch into the
+// registers of t's row; then that patch's column transforms.  FIRST: the accumulators start here (from the
+// batch-norm shift).  wcur: this K step's weights [36][64]; wnxt: the block whose first W43_RING entries the last
+// two rows fetch (the next K step, or the next layer); wo: the lane's byte offset inside a row of weights.
+template <int S, bool FIRST>
+__device__ __forceinline__ void w43_kstep(const float *pnext, bool more, float (&t)[36], f32x4 (&acc)[36], float (&w)[W43_RING],
+                                          const char *wcur, const char *wnxt, unsigned wo, float sh)
+{
+    using G = Geo<S>;
     const f32x4 shv = (f32x4){sh, sh, sh, sh}, zero = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 acc[36];
-    static_for<KS * 6>([&](auto rr) {
-        constexpr int R = decltype(rr)::value, ks = R / 6, i = R % 6;
+    static_for<6>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
         __builtin_amdgcn_sched_barrier(0);
         float a6[6];
         w43_bt(t[i * 6], t[i * 6 + 1], t[i * 6 + 2], t[i * 6 + 3], t[i * 6 + 4], t[i * 6 + 5], a6[0], a6[1], a6[2], a6[3], a6[4], a6[5]);
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-            const int x = i * 6 + j, g = R * 6 + j;
-            if (ks == 0) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a6[j], w[g % W43_RING], x == 7 ? shv : zero, 0, 0, 0);
-            else acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a6[j], w[g % W43_RING], acc[x], 0, 0, 0);
+            const int x = i * 6 + j;
+            if (FIRST) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a6[j], w[x % W43_RING], x == 7 ? shv : zero, 0, 0, 0);
+            else acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a6[j], w[x % W43_RING], acc[x], 0, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < 6; j++) { // the ring: the weights of the row after the next
-            const int g = R * 6 + j + W43_RING;
-            const float *src = g < KS * 36 ? layer + g * 64 : nextp + (g - KS * 36) * 64;
-            w[g % W43_RING] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(src) + wo);
+        for (int j = 0; j < 6; j++) {
+            const int g = i * 6 + j + W43_RING;
+            const char *src = g < 36 ? wcur + g * 256 : wnxt + (g - 36) * 256;
+            w[g % W43_RING] = *reinterpret_cast<const float *>(src + wo);
         }
-        if constexpr (ks + 1 < KS) { // the same row of the next K step's patch; its column transforms once the patch is complete
-            const float *p = p0 + (ks + 1) * 4 * G::PS + i * G::ROW;
+        if (more) {
+            const float *p = pnext + i * G::ROW;
 #pragma unroll
             for (int j = 0; j < 6; j++) t[i * 6 + j] = p[j];
-            if constexpr (i == 5) {
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 6; j++)
-                    w43_bt(t[j], t[6 + j], t[12 + j], t[18 + j], t[24 + j], t[30 + j], t[j], t[6 + j], t[12 + j], t[18 + j], t[24 + j],
-                           t[30 + j]);
-            }
         }
     });
     __builtin_amdgcn_sched_barrier(0);
+    if (more) w43_columns(t);
+}
+
+// One 3x3 layer, in place.  ksteps: 4 for 16 input channels, 1 for the two input planes (K indices 2..3 carry zero
+// weights and read planes 0..1 again).  `layer`: the layer's weights [ksteps][36][64] in the order the matrix
+// instructions take them; w[] holds the first W43_RING of them on entry and the first W43_RING of `nextp` (the
+// layer that runs next) on return.  wr / keep / sum: what happens to the outputs (w43_emit).
+template <int S>
+__device__ __forceinline__ void w43_layer(float *buf, float (&w)[W43_RING], const float *layer, const float *nextp, float sh, int lane,
+                                          int ksteps, bool wr, bool keep, bool sum, float *fc, int fz, float &lsum)
+{
+    using G = Geo<S>;
+    int l = lane;
+    asm volatile("" : "+v"(l)); // (addresses are formed per layer instead of living in registers across the position loop)
+    const int kq = l >> 4, co = l & 15;
+    const int kqp = ksteps == 4 ? kq : (kq & 1); // plane of this lane's K index in K step 0
+    const unsigned wo = (unsigned)l * 4u;
+    const float *p0 = buf + kqp * G::PS + 4 * (co >> 2) * G::ROW + 4 * (co & 3); // channels and cells are constant offsets from here
+    float t[36];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) t[i * 6 + j] = p0[i * G::ROW + j];
+    w43_columns(t);
+    f32x4 acc[36];
+    const char *wl = reinterpret_cast<const char *>(layer), *wn = reinterpret_cast<const char *>(nextp);
+    __builtin_amdgcn_s_setprio(AZ_W43_PRIO_ROWS);
+    w43_kstep<S, true>(p0 + 4 * G::PS, ksteps > 1, t, acc, w, wl, ksteps > 1 ? wl + 36 * 256 : wn, wo, sh);
+#pragma nounroll
+    for (int ks = 1; ks < ksteps; ks++) {
+        const bool more = ks + 1 < ksteps;
+        w43_kstep<S, false>(p0 + (ks + 1) * 4 * G::PS, more, t, acc, w, wl + ks * 36 * 256, more ? wl + (ks + 1) * 36 * 256 : wn, wo, sh);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(AZ_W43_PRIO_OUT);
     const int cob = co * G::PS + (4 * kq + 1) * G::ROW + 1;
-    static_for<4>([&](auto rr) {
-        constexpr int r = decltype(rr)::value;
-        float s[4][6], y[4][4];
+    // Y = At M A, two tiles side by side (the components of an accumulator are consecutive registers)
+    static_for<2>([&](auto hh) {
+        constexpr int h = decltype(hh)::value;
+        f32x2 m[36], s2[4][6], y2[4][4];
 #pragma unroll
-        for (int j = 0; j < 6; j++)
-            w43_at(acc[j][r], acc[6 + j][r], acc[12 + j][r], acc[18 + j][r], acc[24 + j][r], acc[30 + j][r], s[0][j], s[1][j], s[2][j],
-                   s[3][j]);
+        for (int x = 0; x < 36; x++) m[x] = h == 0 ? __builtin_shufflevector(acc[x], acc[x], 0, 1) : __builtin_shufflevector(acc[x], acc[x], 2, 3);
 #pragma unroll
-        for (int q = 0; q < 4; q++) w43_at(s[q][0], s[q][1], s[q][2], s[q][3], s[q][4], s[q][5], y[q][0], y[q][1], y[q][2], y[q][3]);
-        w43_emit<S, wr, keep, sum, r>(buf, cob, kq, y, fc, fz, lsum);
+        for (int j = 0; j < 6; j++) w43_at(m[j], m[6 + j], m[12 + j], m[18 + j], m[24 + j], m[30 + j], s2[0][j], s2[1][j], s2[2][j], s2[3][j]);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            w43_at(s2[q][0], s2[q][1], s2[q][2], s2[q][3], s2[q][4], s2[q][5], y2[q][0], y2[q][1], y2[q][2], y2[q][3]);
+        float y[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int b2 = 0; b2 < 4; b2++) y[q][b2] = y2[q][b2][0];
+        w43_emit<S, 2 * h>(buf, cob, kq, y, wr, keep, sum, fc, fz, lsum);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int b2 = 0; b2 < 4; b2++) y[q][b2] = y2[q][b2][1];
+        w43_emit<S, 2 * h + 1>(buf, cob, kq, y, wr, keep, sum, fc, fz, lsum);
     });
 }
 
@@ -245,12 +323,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
     };
     if (n_mine > 0) request_board(listed ? todo[0] : (int)blockIdx.x);
-    const float *first16 = nl > 0 ? layer_params(0) : p_first; // the layer behind the input layer
     float w[W43_RING]; // the weight ring: starts with the input layer's first rows, every layer refills it for the next
 #pragma unroll
     for (int g = 0; g < W43_RING; g++) w[g] = p_first[g * 64 + lane];
     const float u0sh = p_first[36 * 64 + co];
-    float ush = nl > 0 ? layer_params(0)[4 * 36 * 64 + co] : 0.f;
+    float ush = 0.f;
     for (int it = 0; it < n_mine; it++) {
         const int pos = listed ? todo[it] : (int)blockIdx.x + it * (int)gridDim.x;
 #ifdef AZ_NET_STAMPS
@@ -267,35 +344,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         __syncthreads();
         NST(0);
-        float vsum = 0.f, lsum = 0.f;
-        // input layer; it is also the trunk's last layer when front == 1
-        if (front > 1) w43_layer<S, 1, true, false, false>(buf, w, p_first, first16, u0sh, lane, fc, fz, lsum);
-        else if (val > 0) w43_layer<S, 1, true, true, false>(buf, w, p_first, first16, u0sh, lane, fc, fz, lsum);
-        else w43_layer<S, 1, true, false, true>(buf, w, p_first, first16, u0sh, lane, fc, fz, lsum);
-        if (front == 1 && val == 0) vsum = lsum;
-        __syncthreads();
-        NST(6);
-        for (int e = 0; e < nl; e++) {
+        float vsum = 0.f;
+        // e = -1: the input layer (also the trunk's last layer when front == 1), then the 16-channel layers in execution order
+        for (int e = -1; e < nl; e++) {
             const bool last_trunk = e == front - 2;
             const bool last_value = val > 0 && e == front - 1 + val - 1;
             const bool first_policy = pol > 0 && e == front - 1 + val;
-            const float *layer = layer_params(e);
+            const float *layer = e < 0 ? p_first : layer_params(e);
             const float *nextp = e + 1 < nl ? layer_params(e + 1) : p_first; // (the last layer fetches the next position's first)
             if (first_policy && val > 0) { // the trunk output comes back
                 w43_restore<S>(buf, lane, fc, fz);
                 __syncthreads();
             }
-            const float sh = ush;
-            ush = layer_params(e + 1 < nl ? e + 1 : 0)[4 * 36 * 64 + co]; // (requested a layer ahead: its latency runs under this layer)
-            lsum = 0.f;
+            const float sh = e < 0 ? u0sh : ush;
+            if (e >= 0 || nl > 0) ush = layer_params(e + 1 < nl ? e + 1 : 0)[4 * 36 * 64 + co]; // (requested a layer ahead)
             NST(4);
-            if (last_value) w43_layer<S, 4, false, false, true>(buf, w, layer, nextp, sh, lane, fc, fz, lsum);
-            else if (last_trunk && val > 0) w43_layer<S, 4, true, true, false>(buf, w, layer, nextp, sh, lane, fc, fz, lsum);
-            else if (last_trunk) w43_layer<S, 4, true, false, true>(buf, w, layer, nextp, sh, lane, fc, fz, lsum);
-            else w43_layer<S, 4, true, false, false>(buf, w, layer, nextp, sh, lane, fc, fz, lsum);
-            if (last_value || (last_trunk && val == 0)) vsum = lsum;
+            float lsum = 0.f;
+            const bool sum = last_value || (last_trunk && val == 0);
+            w43_layer<S>(buf, w, layer, nextp, sh, lane, e < 0 ? 1 : 4, !last_value, last_trunk && val > 0, sum, fc, fz, lsum);
+            if (sum) vsum = lsum;
             __syncthreads();
-            NST(1);
+            if (e < 0) NST(6);
+            else NST(1);
         }
         // policy head input: the policy branch's output, or the trunk output when there is no such branch
         if (pol == 0 && val > 0) {

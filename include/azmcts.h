@@ -322,8 +322,9 @@ int az_net_param_floats(int front_layers, int policy_layers, int value_layers);
 /* Which kernel az_net_eval runs (no counterpart in the reference; for tuning and for
  * tests that compare the forms): AUTO = the direct-form team kernel for batches of at most one
  * position per CU (two above 15x15), otherwise by board size (one wavefront per position and two
- * per SIMD up to 15x15, the 3x3 layers in the Winograd F(2x2,3x3) form from 12x12 on; the
- * Winograd kernel with one wavefront per SIMD above 15x15); DIRECT / WINOGRAD = that form
+ * per SIMD up to 14x14, the 3x3 layers in the Winograd F(2x2,3x3) form from 12x12 on; the
+ * Winograd F(4x4,3x3) kernel at 15x15 and 16x16; the F(2x2,3x3) kernel with one wavefront per
+ * SIMD above 16x16); DIRECT / WINOGRAD = that form
  * of the 3x3 layers for every size (one wavefront per position up to 15x15, a team of
  * four above; DIRECT above 15x15 is the same as TEAM); TEAM = the direct-form team kernel
  * for every size; WIDE = the one-wavefront-per-SIMD Winograd kernel from 12x12 on (AUTO's

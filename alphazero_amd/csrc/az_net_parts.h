@@ -189,7 +189,8 @@ template <int S> struct WideGeo {
 // M = 16 cells of one board row (two tiles per row above 16 cells; lanes past the row end read its right
 // halo cell, zero, and what they store is zero and lands on that cell again).  A cell's product reads and
 // writes that cell only, so the rows go in groups: all reads of a group precede its writes.
-template <int S> __device__ __forceinline__ void policy_taps_wide(float *buf, const float (&wpb)[4], int lane)
+// A team of `team` wavefronts shares the groups: wavefront `member` (wave-uniform) takes every team-th of them.
+template <int S> __device__ __forceinline__ void policy_taps_wide(float *buf, const float (&wpb)[4], int lane, int member = 0, int team = 1)
 {
     using G = Geo<S>;
     constexpr int TPR = WideGeo<S>::TPR, RG = 5, NG = (S + RG - 1) / RG; // RG board rows per group
@@ -198,6 +199,7 @@ template <int S> __device__ __forceinline__ void policy_taps_wide(float *buf, co
     const int co = l & 15, kq = l >> 4;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
+        if (team > 1 && g % team != member) continue;
         const int rows = (g + 1) * RG <= S ? RG : S - g * RG;
         f32x4 acc[RG * TPR];
 #pragma unroll

@@ -435,6 +435,276 @@ template <int S> int launch_w43(const float *boards, const int *leaf_kind, const
     return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
 }
 
+// ---------------------------------------------------------------------------------
+// 20x20: a 5x5 grid of tiles = two blocks of 16 (seven dummies), a TEAM of two wavefronts per position, one block
+// each (a board of that size fills 31 KB of LDS: four positions per CU, and two wavefronts per SIMD need eight
+// wavefronts).  Both wavefronts read their patches from the one buffer and write their outputs back into it, so a
+// barrier separates a layer's last patch read from its first store; the heads split the board rows.
+template <int S_> struct W43TeamGeo {
+    using G = Geo<S_>;
+    static_assert(S_ == 20, "tiles that end on the board edge (patches end on the halo, no partial tiles)");
+    static constexpr int S = S_, SIZE = G::SIZE, ROW = G::ROW, PS = G::PS; // (what policy_softmax reads)
+    static constexpr int NW = 2, NTHR = 128;
+    static constexpr int TW = S / 4, TILES = TW * TW;
+    static constexpr unsigned DIV = 65536 / TW + 1; // T / TW == (T * DIV) >> 16 for T < 128
+    static constexpr int TAIL = 64;
+    static constexpr int LDS_BYTES = (G::BUF + TAIL + 16 + SIZE) * 4; // buffer, zero tail, reduction cells, logits
+    static constexpr int WGS0 = (160 * 1024 - 2048) / (LDS_BYTES + 256);
+    static constexpr int WGS = WGS0 > 4 ? 4 : WGS0;
+    static_assert(TILES <= 32 && WGS >= 1, "two blocks");
+};
+
+// w43_emit for a tile whose place is a run-time value (T: tile index, tiles past the grid are dummies); R: the slot of
+// the tile in the lane's private copy
+template <int S, int R>
+__device__ __forceinline__ void w43t_emit(float *buf, int co, unsigned T, float (&y)[4][4], bool wr, bool keep, bool sum, float *fc, int fz,
+                                          float &lsum)
+{
+    using G = Geo<S>;
+    using W = W43TeamGeo<S>;
+    const bool valid = T < (unsigned)W::TILES;
+    const unsigned ty = (T * W::DIV) >> 16, tx = T - ty * W::TW;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const float v = __builtin_amdgcn_fmed3f(y[a][b], 0.f, INFINITY);
+            y[a][b] = valid ? v : 0.f;
+        }
+    if (wr && valid) {
+        float *c = buf + co * G::PS + (int)((4 * ty + 1) * G::ROW + 4 * tx + 1);
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) c[a * G::ROW + b] = y[a][b];
+    }
+    if (sum) {
+#pragma unroll
+        for (int a = 0; a < 4; a++) lsum += (y[a][0] + y[a][1]) + (y[a][2] + y[a][3]);
+    }
+    if (keep) {
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) fc[fz + (a * 4 + b) * 4 + R] = y[a][b];
+    }
+}
+
+template <int S> __device__ __forceinline__ void w43t_restore(float *buf, int wave, int lane, const float *fc, int fz)
+{
+    using G = Geo<S>;
+    using W = W43TeamGeo<S>;
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    const int co = l & 15, kq = l >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const unsigned T = (unsigned)(16 * wave + 4 * kq + r);
+        const unsigned ty = (T * W::DIV) >> 16, tx = T - ty * W::TW;
+        if (T < (unsigned)W::TILES) {
+            float *c = buf + co * G::PS + (int)((4 * ty + 1) * G::ROW + 4 * tx + 1);
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) c[a * G::ROW + b] = fc[fz + (a * 4 + b) * 4 + r];
+        }
+    }
+}
+
+// w43_layer for the block of tiles of wavefront `wave` of a team; contains one barrier (every wavefront of the
+// workgroup has to call it)
+template <int S>
+__device__ __forceinline__ void w43t_layer(float *buf, float (&w)[W43_RING], const float *layer, const float *nextp, float sh, int wave,
+                                           int lane, int ksteps, bool wr, bool keep, bool sum, float *fc, int fz, float &lsum)
+{
+    using G = Geo<S>;
+    using W = W43TeamGeo<S>;
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    const int kq = l >> 4, co = l & 15;
+    const int kqp = ksteps == 4 ? kq : (kq & 1);
+    const unsigned wo = (unsigned)l * 4u;
+    unsigned Tin = (unsigned)(16 * wave + co);
+    Tin = Tin < (unsigned)W::TILES ? Tin : (unsigned)W::TILES - 1; // (a dummy tile reads the last tile again)
+    const unsigned pty = (Tin * W::DIV) >> 16, ptx = Tin - pty * W::TW;
+    const float *p0 = buf + kqp * G::PS + (int)(4 * pty * G::ROW + 4 * ptx);
+    float t[36];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) t[i * 6 + j] = p0[i * G::ROW + j];
+    w43_columns(t);
+    f32x4 acc[36];
+    const char *wl = reinterpret_cast<const char *>(layer), *wn = reinterpret_cast<const char *>(nextp);
+    __builtin_amdgcn_s_setprio(AZ_W43_PRIO_ROWS);
+    w43_kstep<S, true>(p0 + 4 * G::PS, ksteps > 1, t, acc, w, wl, ksteps > 1 ? wl + 36 * 256 : wn, wo, sh);
+#pragma nounroll
+    for (int ks = 1; ks < ksteps; ks++) {
+        const bool more = ks + 1 < ksteps;
+        w43_kstep<S, false>(p0 + (ks + 1) * 4 * G::PS, more, t, acc, w, wl + ks * 36 * 256, more ? wl + (ks + 1) * 36 * 256 : wn, wo, sh);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(AZ_W43_PRIO_OUT);
+    __syncthreads(); // both wavefronts have read their patches: the outputs may overwrite them
+    static_for<2>([&](auto hh) {
+        constexpr int h = decltype(hh)::value;
+        f32x2 m[36], s2[4][6], y2[4][4];
+#pragma unroll
+        for (int x = 0; x < 36; x++) m[x] = h == 0 ? __builtin_shufflevector(acc[x], acc[x], 0, 1) : __builtin_shufflevector(acc[x], acc[x], 2, 3);
+#pragma unroll
+        for (int j = 0; j < 6; j++) w43_at(m[j], m[6 + j], m[12 + j], m[18 + j], m[24 + j], m[30 + j], s2[0][j], s2[1][j], s2[2][j], s2[3][j]);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            w43_at(s2[q][0], s2[q][1], s2[q][2], s2[q][3], s2[q][4], s2[q][5], y2[q][0], y2[q][1], y2[q][2], y2[q][3]);
+        float y[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int b2 = 0; b2 < 4; b2++) y[q][b2] = y2[q][b2][0];
+        w43t_emit<S, 2 * h>(buf, co, (unsigned)(16 * wave + 4 * kq + 2 * h), y, wr, keep, sum, fc, fz, lsum);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int b2 = 0; b2 < 4; b2++) y[q][b2] = y2[q][b2][1];
+        w43t_emit<S, 2 * h + 1>(buf, co, (unsigned)(16 * wave + 4 * kq + 2 * h + 1), y, wr, keep, sum, fc, fz, lsum);
+    });
+}
+
+template <int S>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_w43t(
+    const float *boards, const int *leaf_kind, const unsigned *expand_mask, int n, const float *prm, int front, int pol, int val,
+    float *value_out, float *logp_out)
+{
+    using G = Geo<S>;
+    using W = W43TeamGeo<S>;
+    extern __shared__ float lds[];
+    float *buf = lds;
+    float *red = lds + G::BUF + W::TAIL; // [16]: two reduction rows of up to 8 wavefronts
+    float *logit = red + 16;             // [SIZE]
+    int *todo = reinterpret_cast<int *>(logit + G::SIZE); // [ceil(n / gridDim.x)] positions of this workgroup
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co = lane & 15, kq = lane >> 4;
+    for (int i = tid; i < G::BUF + W::TAIL; i += W::NTHR) buf[i] = 0.f; // halos (and the tail) stay zero from here on
+    __syncthreads();
+    const int nl = front - 1 + pol + val;
+    const float *p_policy = prm + FIRST_FLOATS + (size_t)nl * LAYER_FLOATS;
+    const float *p_value = p_policy + POLICY_FLOATS;
+    const float *p_w43 = p_value + VALUE_FLOATS + (size_t)nl * WINO_FLOATS + WINO_FIRST_FLOATS;
+    // execution order: trunk, value branch, policy branch (parameter order: trunk, policy, value)
+    auto layer_params = [&](int e) {
+        const int idx = e < front - 1 ? e : (e < front - 1 + val ? e + pol : e - val);
+        return p_w43 + (size_t)idx * W43_FLOATS;
+    };
+    const float *p_first = p_w43 + (size_t)nl * W43_FLOATS;
+    float wpb[4]; // policy head as a B operand: B[k = ci][n = tap]
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) wpb[ks] = co < 9 ? p_policy[co * CH + ks * 4 + kq] : 0.f;
+    const float p_bias = p_policy[9 * CH];
+    const float wv = p_value[co], v_bias = p_value[CH];
+
+    int n_mine;
+    const bool listed = expand_mask != nullptr || leaf_kind != nullptr; // positions come from todo[]
+    if (expand_mask != nullptr) {
+        n_mine = list_positions_mask(expand_mask, n, todo, lane); // (both wavefronts write the same list)
+    } else if (leaf_kind != nullptr) {
+        n_mine = list_positions<W::NTHR>(leaf_kind, n, todo, reinterpret_cast<int *>(red), tid);
+    } else {
+        n_mine = n > (int)blockIdx.x ? (n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    }
+    __syncthreads();
+
+    float fc[64]; // the trunk output of this wavefront's tiles, parked in private memory while the value branch owns the buffer
+    int fz;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(fz));
+    constexpr int PPL = (G::SIZE + W::NTHR - 1) / W::NTHR; // pixels this thread loads: tid, tid + 128, ...
+    float in0[PPL], in1[PPL];                             // the next position's input planes, requested one position ahead
+    auto request_board = [&](int pos) {
+        const float *bp = boards + (size_t)pos * CIN * G::SIZE;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) {
+            const int p = tid + W::NTHR * i;
+            in0[i] = p < G::SIZE ? bp[p] : 0.f;
+            in1[i] = p < G::SIZE ? bp[G::SIZE + p] : 0.f;
+        }
+    };
+    if (n_mine > 0) request_board(listed ? todo[0] : (int)blockIdx.x);
+    float w[W43_RING];
+#pragma unroll
+    for (int g = 0; g < W43_RING; g++) w[g] = p_first[g * 64 + lane];
+    const float u0sh = p_first[36 * 64 + co];
+    float ush = 0.f;
+    for (int it = 0; it < n_mine; it++) {
+        const int pos = listed ? todo[it] : (int)blockIdx.x + it * (int)gridDim.x;
+#pragma unroll
+        for (int i = 0; i < PPL; i++) { // the two input planes (requested while the previous position was in its heads)
+            const int p = tid + W::NTHR * i;
+            if (p < G::SIZE) {
+                const int ctr = pix_index<S>(p);
+                buf[ctr] = in0[i];
+                buf[G::PS + ctr] = in1[i];
+            }
+        }
+        __syncthreads();
+        float vsum = 0.f;
+        // e = -1: the input layer (also the trunk's last layer when front == 1), then the 16-channel layers in execution order
+        for (int e = -1; e < nl; e++) {
+            const bool last_trunk = e == front - 2;
+            const bool last_value = val > 0 && e == front - 1 + val - 1;
+            const bool first_policy = pol > 0 && e == front - 1 + val;
+            const float *layer = e < 0 ? p_first : layer_params(e);
+            const float *nextp = e + 1 < nl ? layer_params(e + 1) : p_first; // (the last layer fetches the next position's first)
+            if (first_policy && val > 0) { // the trunk output comes back
+                w43t_restore<S>(buf, wave, lane, fc, fz);
+                __syncthreads();
+            }
+            const float sh = e < 0 ? u0sh : ush;
+            if (e >= 0 || nl > 0) ush = layer_params(e + 1 < nl ? e + 1 : 0)[4 * 36 * 64 + co]; // (requested a layer ahead)
+            float lsum = 0.f;
+            const bool sum = last_value || (last_trunk && val == 0);
+            w43t_layer<S>(buf, w, layer, nextp, sh, wave, lane, e < 0 ? 1 : 4, !last_value, last_trunk && val > 0, sum, fc, fz, lsum);
+            if (sum) vsum = lsum;
+            __syncthreads();
+        }
+        // policy head input: the policy branch's output, or the trunk output when there is no such branch
+        if (pol == 0 && val > 0) {
+            w43t_restore<S>(buf, wave, lane, fc, fz);
+            __syncthreads();
+        }
+        // ---- value head: board average of the 1x1 convolution + bias, tanh
+        const float vpart = wave_reduce<false>(wv * vsum);
+        if (it + 1 < n_mine) request_board(listed ? todo[it + 1] : (int)blockIdx.x + (it + 1) * (int)gridDim.x);
+        // ---- policy head: per-tap partial planes on the matrix cores, written over the input; the wavefronts share the row groups
+        policy_taps_wide<S>(buf, wpb, lane, wave, W::NW);
+        if (lane == 0) red[wave] = vpart;
+        __syncthreads();
+        if (tid == 0) value_out[pos] = tanhf((red[0] + red[1]) / (float)G::SIZE + v_bias);
+        __syncthreads(); // red is reused by the softmax
+        policy_softmax<W>(buf, p_bias, red, logit, logp_out + (size_t)pos * G::SIZE, tid, wave, lane);
+        __syncthreads(); // the gather is over before the next position's input lands in the buffer
+    }
+}
+
+template <int S> int launch_w43t(const float *boards, const int *leaf_kind, const unsigned *expand_mask, int n, const float *prm,
+                                 int front, int pol, int val, float *value_out, float *logp_out, hipStream_t st)
+{
+    using W = W43TeamGeo<S>;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int grid = cus * W::WGS;
+    if (grid > n) grid = n;
+    const size_t lds_bytes = (size_t)W::LDS_BYTES + (size_t)((n + grid - 1) / grid) * sizeof(int);
+    static size_t configured[64] = {}; // largest size the kernel has been opened up to, per device
+    if (dev < 0 || dev >= 64 || lds_bytes > configured[dev]) {
+        if (hipFuncSetAttribute((const void *)k_net_w43t<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return AZ_ERR_HIP;
+        if (dev >= 0 && dev < 64) configured[dev] = lds_bytes;
+    }
+    hipLaunchKernelGGL(k_net_w43t<S>, dim3(grid), dim3(W::NTHR), lds_bytes, st, boards, leaf_kind, expand_mask, n, prm, front, pol, val,
+                       value_out, logp_out);
+    return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
+}
+
 } // namespace
 
 // Launches the F(4x4,3x3) kernel; AZ_ERR_ARG for a board size it is not built for.  Arguments as az_net_eval_masked.
@@ -449,6 +719,9 @@ int az_net_w43_launch(int shape, int n, const float *d_boards, const int *d_leaf
     case 16:
         return launch_w43<16>(d_boards, d_leaf_kind, d_expand_mask, n, d_params, front_layers, policy_layers, value_layers, d_value,
                               d_logp, st);
+    case 20:
+        return launch_w43t<20>(d_boards, d_leaf_kind, d_expand_mask, n, d_params, front_layers, policy_layers, value_layers, d_value,
+                               d_logp, st);
     default: return AZ_ERR_ARG;
     }
 }

@@ -207,10 +207,22 @@ __device__ __forceinline__ void w43_kstep(const float *pnext, bool more, float (
 // weights and read planes 0..1 again).  `layer`: the layer's weights [ksteps][36][64] in the order the matrix
 // instructions take them; w[] holds the first W43_RING of them on entry and the first W43_RING of `nextp` (the
 // layer that runs next) on return.  wr / keep / sum: what happens to the outputs (w43_emit).
+#ifdef AZ_NET_STAMPS // diagnostic build: cycle sums of the layer's phases (prologue, K steps, output transform + stores)
+#define W43_STAMP_PARAM , unsigned long long (&stl)[4]
+#define W43_STAMP_ARG , stl
+#define LST(i) do { unsigned long long t_ = __builtin_readcyclecounter(); stl[i] += t_ - stl[3]; stl[3] = t_; } while (0)
+#else
+#define W43_STAMP_PARAM
+#define W43_STAMP_ARG
+#define LST(i) do { } while (0)
+#endif
 template <int S>
 __device__ __forceinline__ void w43_layer(float *buf, float (&w)[W43_RING], const float *layer, const float *nextp, float sh, int lane,
-                                          int ksteps, bool wr, bool keep, bool sum, float *fc, int fz, float &lsum)
+                                          int ksteps, bool wr, bool keep, bool sum, float *fc, int fz, float &lsum W43_STAMP_PARAM)
 {
+#ifdef AZ_NET_STAMPS
+    stl[3] = __builtin_readcyclecounter();
+#endif
     using G = Geo<S>;
     int l = lane;
     asm volatile("" : "+v"(l)); // (addresses are formed per layer instead of living in registers across the position loop)
@@ -224,6 +236,7 @@ __device__ __forceinline__ void w43_layer(float *buf, float (&w)[W43_RING], cons
 #pragma unroll
         for (int j = 0; j < 6; j++) t[i * 6 + j] = p0[i * G::ROW + j];
     w43_columns(t);
+    LST(0);
     f32x4 acc[36];
     const char *wl = reinterpret_cast<const char *>(layer), *wn = reinterpret_cast<const char *>(nextp);
     __builtin_amdgcn_s_setprio(AZ_W43_PRIO_ROWS);
@@ -235,6 +248,10 @@ __device__ __forceinline__ void w43_layer(float *buf, float (&w)[W43_RING], cons
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(AZ_W43_PRIO_OUT);
+#ifdef AZ_NET_STAMPS
+    asm volatile("s_nop 0" ::"v"(acc[35][3])); // (the last matrix instruction has delivered)
+#endif
+    LST(1);
     const int cob = co * G::PS + (4 * kq + 1) * G::ROW + 1;
     // Y = At M A, two tiles side by side (the components of an accumulator are consecutive registers)
     static_for<2>([&](auto hh) {
@@ -259,6 +276,7 @@ __device__ __forceinline__ void w43_layer(float *buf, float (&w)[W43_RING], cons
             for (int b2 = 0; b2 < 4; b2++) y[q][b2] = y2[q][b2][1];
         w43_emit<S, 2 * h + 1>(buf, cob, kq, y, wr, keep, sum, fc, fz, lsum);
     });
+    LST(2);
 }
 
 template <int S>
@@ -301,7 +319,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     __syncthreads(); // (a single wavefront: orders the LDS traffic)
 
 #ifdef AZ_NET_STAMPS
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_0 = __builtin_readcyclecounter();
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_0 = __builtin_readcyclecounter(), stl[4] = {0, 0, 0, 0};
 #define NST(i) do { unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_t; st_t = t_; } while (0)
 #else
 #define NST(i) do { } while (0)
@@ -361,7 +379,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             NST(4);
             float lsum = 0.f;
             const bool sum = last_value || (last_trunk && val == 0);
-            w43_layer<S>(buf, w, layer, nextp, sh, lane, e < 0 ? 1 : 4, !last_value, last_trunk && val > 0, sum, fc, fz, lsum);
+            w43_layer<S>(buf, w, layer, nextp, sh, lane, e < 0 ? 1 : 4, !last_value, last_trunk && val > 0, sum, fc, fz, lsum W43_STAMP_ARG);
             if (sum) vsum = lsum;
             __syncthreads();
             if (e < 0) NST(6);
@@ -410,6 +428,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         st_acc[5] = __builtin_readcyclecounter() - st_0;
         st_acc[7] = (unsigned long long)n_mine;
         unsigned long long *o = reinterpret_cast<unsigned long long *>(logp_out + (size_t)blockIdx.x * G::SIZE);
+        st_acc[2] = stl[0] * 1000000ull + stl[1] / 8; // (prologues, K steps / 8)
+        st_acc[0] = stl[2]; // (output transforms and stores; replaces the input load)
         for (int q = 0; q < 8; q++) o[q] = st_acc[q];
     }
 #endif

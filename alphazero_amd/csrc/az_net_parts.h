@@ -17,8 +17,8 @@ namespace aznet {
 // Winograd F(2x2,3x3) domain, then the input layer in that domain, then both again in the F(4x4,3x3) domain.
 constexpr int WINO_FLOATS = 64 * 64 + CH; // U[16 positions][4 K steps][64 lanes], shift[16]
 constexpr int WINO_FIRST_FLOATS = 16 * 64 + CH; // input layer: U[16 positions][64 lanes] (zero for the lanes of K indices 2..3), shift[16]
-constexpr int W43_FLOATS = 4 * 36 * 64 + CH; // U[4 K steps][36 positions][64 lanes], shift[16]
-constexpr int W43_FIRST_FLOATS = 36 * 64 + CH; // input layer: U[36 positions][64 lanes] (zero for the lanes of K indices 2..3), shift[16]
+constexpr int W43_FLOATS = 4 * 36 * 64 + CH; // U[4 K steps][18 pairs of positions][64 lanes][2], shift[16]
+constexpr int W43_FIRST_FLOATS = 36 * 64 + CH; // input layer: U[18 pairs of positions][64 lanes][2] (zero for the lanes of K indices 2..3), shift[16]
 
 // Which positions a workgroup evaluates: those whose code is AZ_LEAF_EXPAND (a search that ended
 // on a finished game, or an idle tree, needs no evaluation), split evenly over the workgroups in

@@ -168,7 +168,7 @@ __device__ __forceinline__ void w43_columns(float (&t)[36])
 // One K step: row by row the row transform of t (six A operands), six matrix instructions, the six weights of the
 // row after the next into the ring slots just used, and (more) the same row of the next K step's patch into the
 // registers of t's row; then that patch's column transforms.  FIRST: the accumulators start here (from the
-// batch-norm shift).  wcur: this K step's weights [36][64]; wnxt: the block whose first W43_RING entries the last
+// batch-norm shift).  wcur: this K step's weights [18 pairs][64 lanes][2]; wnxt: the block whose first W43_RING entries the last
 // two rows fetch (the next K step, or the next layer); wo: the lane's byte offset inside a row of weights.
 template <int S, bool FIRST>
 __device__ __forceinline__ void w43_kstep(const float *pnext, bool more, float (&t)[36], f32x4 (&acc)[36], float (&w)[W43_RING],
@@ -188,10 +188,12 @@ __device__ __forceinline__ void w43_kstep(const float *pnext, bool more, float (
             else acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(a6[j], w[x % W43_RING], acc[x], 0, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
+        for (int j = 0; j < 6; j += 2) { // (weights lie in pairs per lane: one 8-byte request per two matrix instructions)
             const int g = i * 6 + j + W43_RING;
-            const char *src = g < 36 ? wcur + g * 256 : wnxt + (g - 36) * 256;
-            w[g % W43_RING] = *reinterpret_cast<const float *>(src + wo);
+            const char *src = g < 36 ? wcur + (g / 2) * 512 : wnxt + ((g - 36) / 2) * 512;
+            const f32x2 v = *reinterpret_cast<const f32x2 *>(src + wo);
+            w[g % W43_RING] = v[0];
+            w[(g + 1) % W43_RING] = v[1];
         }
         if (more) {
             const float *p = pnext + i * G::ROW;
@@ -228,7 +230,7 @@ __device__ __forceinline__ void w43_layer(float *buf, float (&w)[W43_RING], cons
     asm volatile("" : "+v"(l)); // (addresses are formed per layer instead of living in registers across the position loop)
     const int kq = l >> 4, co = l & 15;
     const int kqp = ksteps == 4 ? kq : (kq & 1); // plane of this lane's K index in K step 0
-    const unsigned wo = (unsigned)l * 4u;
+    const unsigned wo = (unsigned)l * 8u;
     const float *p0 = buf + kqp * G::PS + 4 * (co >> 2) * G::ROW + 4 * (co & 3); // channels and cells are constant offsets from here
     float t[36];
 #pragma unroll
@@ -343,7 +345,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (n_mine > 0) request_board(listed ? todo[0] : (int)blockIdx.x);
     float w[W43_RING]; // the weight ring: starts with the input layer's first rows, every layer refills it for the next
 #pragma unroll
-    for (int g = 0; g < W43_RING; g++) w[g] = p_first[g * 64 + lane];
+    for (int g = 0; g < W43_RING; g += 2) {
+        const f32x2 v = *reinterpret_cast<const f32x2 *>(p_first + (g / 2) * 128 + lane * 2);
+        w[g] = v[0];
+        w[g + 1] = v[1];
+    }
     const float u0sh = p_first[36 * 64 + co];
     float ush = 0.f;
     for (int it = 0; it < n_mine; it++) {
@@ -543,7 +549,7 @@ __device__ __forceinline__ void w43t_layer(float *buf, float (&w)[W43_RING], con
     asm volatile("" : "+v"(l));
     const int kq = l >> 4, co = l & 15;
     const int kqp = ksteps == 4 ? kq : (kq & 1);
-    const unsigned wo = (unsigned)l * 4u;
+    const unsigned wo = (unsigned)l * 8u;
     unsigned Tin = (unsigned)(16 * wave + co);
     Tin = Tin < (unsigned)W::TILES ? Tin : (unsigned)W::TILES - 1; // (a dummy tile reads the last tile again)
     const unsigned pty = (Tin * W::DIV) >> 16, ptx = Tin - pty * W::TW;
@@ -651,7 +657,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (n_mine > 0) request_board(listed ? todo[0] : (int)blockIdx.x);
     float w[W43_RING];
 #pragma unroll
-    for (int g = 0; g < W43_RING; g++) w[g] = p_first[g * 64 + lane];
+    for (int g = 0; g < W43_RING; g += 2) {
+        const f32x2 v = *reinterpret_cast<const f32x2 *>(p_first + (g / 2) * 128 + lane * 2);
+        w[g] = v[0];
+        w[g + 1] = v[1];
+    }
     const float u0sh = p_first[36 * 64 + co];
     float ush = 0.f;
     for (int it = 0; it < n_mine; it++) {

@@ -160,7 +160,8 @@ class FusedNetEvaluator:
             b[x] = torch.where(kq < 2, uu[co, kq & 1, x // 4, x % 4], torch.zeros(64, dtype=torch.float64))
         out += [b.reshape(-1), sh]
         # Both again in the Winograd F(4x4, 3x3) domain (6x6 transformed positions x = 6*xi + nu), K step
-        # outermost: lane (co, kq) holds U[co, 4*ks + kq, xi, nu] at [ks][x]; then the shift.
+        # outermost: lane (co, kq) holds U[co, 4*ks + kq, xi, nu]; positions in pairs per lane
+        # ([ks][x // 2][lane][x % 2]: one 8-byte load brings two matrix instructions' operands); then the shift.
         gm4 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
                             [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)
         xi, nu = torch.arange(36) // 6, torch.arange(36) % 6
@@ -170,11 +171,11 @@ class FusedNetEvaluator:
             b = torch.zeros(4, 36, 64, dtype=torch.float64)
             for ks in range(4):
                 b[ks] = uu[co.view(1, 64), (4 * ks + kq).view(1, 64), xi.view(36, 1), nu.view(36, 1)]
-            out += [b.reshape(-1), sh]
+            out += [b.view(4, 18, 2, 64).permute(0, 1, 3, 2).reshape(-1), sh]
         w, sc, sh = cls._fold(state, "front", 0)
         uu = gm4 @ (w * sc.view(-1, 1, 1, 1)) @ gm4.T      # [co, 2, 6, 6]
         b = uu[co.view(1, 64), (kq & 1).view(1, 64), xi.view(36, 1), nu.view(36, 1)] * (kq < 2).view(1, 64)
-        out += [b.reshape(-1), sh]
+        out += [b.view(18, 2, 64).permute(0, 2, 1).reshape(-1), sh]
         return torch.cat(out).to(torch.float32).contiguous(), (front, pol, val)
 
     takes_leaf_kinds = True

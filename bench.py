@@ -372,7 +372,10 @@ def secondary_net(torch, E, dev_index, trees=8192, shape=SHAPE, sims=SIMS, label
                                        "note": "achieved = matrix instructions issued x 2048 flops per second (the work "
                                                "the matrix cores execute); direct_form_equivalent prices the same launch "
                                                "with the network's direct-form multiply-adds x 2 (the Winograd kernels "
-                                               "execute about half of them), so it can pass the peak"},
+                                               "execute a third to a half of them), so it can pass the peak; the launch is "
+                                               "timed alone between HIP events with the code-scanning position list, "
+                                               "inside az_simulate_net the same kernel takes a bit mask and runs about "
+                                               "0.03 ms shorter (profiles/r02j_config3_kernel_stats.csv)"},
             }
         finally:
             tb.close()

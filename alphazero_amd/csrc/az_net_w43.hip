@@ -1,5 +1,5 @@
 // Batched policy/value network evaluation (the reference's `simplerNN`, src/model.py:9-44, inference mode),
-// Winograd F(4x4, 3x3) form of the 3x3 layers for boards of 15x15 and 16x16: see az_net.hip for the other forms
+// Winograd F(4x4, 3x3) form of the 3x3 layers for boards of 15x15, 16x16 and (further down) 20x20: see az_net.hip for the other forms
 // and for what is common to all of them (activations of a position resident in LDS, plane-major with a zero halo,
 // every layer in place, f32 matrix instructions v_mfma_f32_16x16x4_f32).
 //
@@ -11,7 +11,7 @@
 //   One wavefront per position, two wavefronts per SIMD (eight positions per CU, no barrier anywhere): a
 //   wavefront alone on a SIMD issues a vector instruction only every 5 - 8 cycles and its vector instructions
 //   do not overlap with its own matrix instructions, two wavefronts fill each other's gaps.  256 registers per
-//   wavefront then: the 36 accumulators of four registers (144, AGPRs) leave 112, so everything else streams.
+//   wavefront then: the 36 accumulators of four registers each leave 112, so everything else streams.
 //   Lane (m, kq) of K step ks loads the 6x6 patch of tile m (tile row m >> 2, tile column m & 3) of channel
 //   4*ks + kq and forms V = Bt d B in two halves: the column transforms of the whole patch (t = Bt d, 72
 //   operations, in the registers of the patch), then ROW BY ROW the row transform (12 operations) whose six
@@ -22,6 +22,8 @@
 //   After the last K step lane (co, kq) holds, for the four tiles of tile row kq and its output channel co, the
 //   36 transformed sums; Y = At M A gives the 4x4 outputs.  The batch-norm shift enters through the initial
 //   value of the one accumulator (transformed position (1, 1)) that feeds every output with weight one.
+//   The order of a row's instructions is the one written here: every row ends in a (wave-uniform) branch, which the
+//   compiler does not schedule across; as one basic block per K step the same code ran 25 % slower.
 // Patches of the last tile row / column reach past the halo: at 15x15 that is the next row's left halo cell, the
 // next plane's top halo or the zero tail behind the last plane; at 16x16 they end on the halo exactly.
 #include <hip/hip_runtime.h>

@@ -25,7 +25,9 @@
 //   The order of a row's instructions is the one written here: every row ends in a (wave-uniform) branch, which the
 //   compiler does not schedule across; as one basic block per K step the same code ran 25 % slower.
 // Patches of the last tile row / column reach past the halo: at 15x15 that is the next row's left halo cell, the
-// next plane's top halo or the zero tail behind the last plane; at 16x16 they end on the halo exactly.
+// next plane's top halo or the zero tail behind the last plane; at 16x16 they end on the halo exactly; at 13x13 and
+// 14x14 they wrap into cells of the next row / the next plane, i.e. finite values that only the outputs outside the
+// board depend on (the others see them through sums that cancel, at the level of the form's rounding).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -42,7 +44,7 @@ using namespace aznet;
 
 template <int S> struct W43Geo {
     using G = Geo<S>;
-    static_assert(S == 15 || S == 16, "a 4x4 grid of tiles whose patches end on zero cells");
+    static_assert(S >= 13 && S <= 16, "a 4x4 grid of tiles; what a patch reads past the board is zero or finite");
     static constexpr int LDS_BYTES = (G::BUF + 64) * 4; // + the zero tail behind the last plane
     static constexpr int WGS0 = (160 * 1024 - 2048) / (LDS_BYTES + 256); // positions per CU: eight at 15x15, seven at 16x16
     static constexpr int WGS = WGS0 > 8 ? 8 : WGS0;
@@ -79,14 +81,23 @@ template <class T> __device__ __forceinline__ void w43_at(T m0, T m1, T m2, T m3
 }
 
 // Stores (wr), adds up (sum) or parks (keep) the 4x4 outputs y[a][b] of the lane's R-th tile (tile row kq, tile
-// column R), ReLU applied here.  Cells outside a 15x15 board are halo cells: the column is skipped, the row
-// receives zero.  cob = co*PS + (4*kq + 1)*ROW + 1.  The flags are wave-uniform run-time values: one instance of
-// the layer serves the whole network (the kernel's code has to stay well inside the instruction cache).
+// column R), ReLU applied here.  Cells outside the board are replaced by zero: their columns are skipped, their rows
+// (last tile row only) go to the halo row below the board, which stays zero that way.  cob = co*PS + (4*kq + 1)*ROW + 1.
+// The flags are wave-uniform run-time values: one instance of the layer serves the whole network (the kernel's code
+// has to stay well inside the instruction cache).
+template <int S> struct W43Rows {
+    static constexpr int LAST = S - 12; // board rows in the last tile row (1..4); row LAST of that tile is the halo row
+};
+// float offset of row a of the lane's tiles from row 0 (rows past the halo row fold onto it)
+template <int S> __device__ __forceinline__ int w43_row_offset(int a, int kq)
+{
+    if (a <= W43Rows<S>::LAST) return a * Geo<S>::ROW;
+    return (kq == 3 ? W43Rows<S>::LAST : a) * Geo<S>::ROW;
+}
 template <int S, int R>
 __device__ __forceinline__ void w43_emit(float *buf, int cob, int kq, float (&y)[4][4], bool wr, bool keep, bool sum, float *fc, int fz,
                                          float &lsum)
 {
-    using G = Geo<S>;
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -94,15 +105,17 @@ __device__ __forceinline__ void w43_emit(float *buf, int cob, int kq, float (&y)
             const bool col_ok = 4 * R + b < S; // (a constant)
             float v = __builtin_amdgcn_fmed3f(y[a][b], 0.f, INFINITY);
             if (!col_ok) v = 0.f;
-            if (S == 15 && a == 3 && col_ok) v = kq == 3 ? 0.f : v;
+            if (a >= W43Rows<S>::LAST && col_ok) v = kq == 3 ? 0.f : v;
             y[a][b] = v;
         }
     if (wr) {
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+        for (int a = 0; a < 4; a++) {
+            const int ro = w43_row_offset<S>(a, kq);
 #pragma unroll
             for (int b = 0; b < 4; b++)
-                if (4 * R + b < S) buf[cob + a * G::ROW + 4 * R + b] = y[a][b];
+                if (4 * R + b < S) buf[cob + ro + 4 * R + b] = y[a][b];
+        }
     }
     if (sum) {
 #pragma unroll
@@ -122,14 +135,17 @@ template <int S> __device__ __forceinline__ void w43_restore(float *buf, int lan
     using G = Geo<S>;
     int l = lane;
     asm volatile("" : "+v"(l));
-    const int cob = (l & 15) * G::PS + (4 * (l >> 4) + 1) * G::ROW + 1;
+    const int kq = l >> 4;
+    const int cob = (l & 15) * G::PS + (4 * kq + 1) * G::ROW + 1;
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+        for (int a = 0; a < 4; a++) {
+            const int ro = w43_row_offset<S>(a, kq);
 #pragma unroll
             for (int b = 0; b < 4; b++)
-                if (4 * r + b < S) buf[cob + a * G::ROW + 4 * r + b] = fc[fz + (a * 4 + b) * 4 + r];
+                if (4 * r + b < S) buf[cob + ro + 4 * r + b] = fc[fz + (a * 4 + b) * 4 + r];
+        }
 }
 
 #ifndef AZ_W43_PK_IN
@@ -745,6 +761,12 @@ int az_net_w43_launch(int shape, int n, const float *d_boards, const int *d_leaf
                       hipStream_t st)
 {
     switch (shape) {
+    case 13:
+        return launch_w43<13>(d_boards, d_leaf_kind, d_expand_mask, n, d_params, front_layers, policy_layers, value_layers, d_value,
+                              d_logp, st);
+    case 14:
+        return launch_w43<14>(d_boards, d_leaf_kind, d_expand_mask, n, d_params, front_layers, policy_layers, value_layers, d_value,
+                              d_logp, st);
     case 15:
         return launch_w43<15>(d_boards, d_leaf_kind, d_expand_mask, n, d_params, front_layers, policy_layers, value_layers, d_value,
                               d_logp, st);

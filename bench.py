@@ -67,7 +67,7 @@ def net_kernel_of(shape):
     instructions (v_mfma_f32_16x16x4_f32, 2048 flops each) it issues per position of the reference
     configuration (4 + 2 + 2 layers): the executed work, as opposed to the network's direct-form count."""
     layers16 = 7
-    if shape in (15, 16):  # Winograd F(4x4,3x3): one block of 16 tiles, 36 transformed positions, 4 K steps per layer
+    if 13 <= shape <= 16:  # Winograd F(4x4,3x3): one block of 16 tiles, 36 transformed positions, 4 K steps per layer
         return ("k_net_w43 (Winograd F(4x4,3x3), one wavefront per position)",
                 layers16 * 144 + 36 + shape * ((shape + 15) // 16) * 4)
     if shape == 20:        # the same with two blocks (5x5 tiles), a team of two wavefronts per position

@@ -59,7 +59,8 @@ def net_form():
                                                      (16, 4, 2, 2, 90), (17, 2, 1, 3, 30), (18, 1, 0, 1, 21), (19, 3, 3, 0, 40),
                                                      (20, 4, 2, 2, 600),
                                                      (15, 1, 0, 0, 40), (15, 2, 0, 1, 33), (16, 1, 1, 0, 25), (15, 3, 1, 0, 2100),
-                                                     (16, 2, 0, 2, 19), (15, 1, 2, 2, 64), (16, 3, 3, 1, 2300)])
+                                                     (16, 2, 0, 2, 19), (15, 1, 2, 2, 64), (16, 3, 3, 1, 2300),
+                                                     (13, 1, 0, 0, 30), (13, 3, 1, 1, 2200), (14, 4, 2, 2, 2100), (14, 1, 2, 0, 45)])
 def test_fused_net_matches_torch_float64(shape, front, pol, val, n, form, net_form):
     """Every kernel form (one wavefront per position with direct or Winograd 3x3 layers, team of
     wavefronts, one wavefront per SIMD) against PyTorch float64, over every branch layout (no policy /
@@ -69,8 +70,8 @@ def test_fused_net_matches_torch_float64(shape, front, pol, val, n, form, net_fo
 
     if shape > 15 and form == "direct":
         pytest.skip("above 15x15 the direct form is the team kernel")
-    if form == "w43" and shape not in (15, 16, 20):
-        pytest.skip("the F(4x4,3x3) kernels are built for 15x15, 16x16 and 20x20")
+    if form == "w43" and shape not in (13, 14, 15, 16, 20):
+        pytest.skip("the F(4x4,3x3) kernels are built for 13x13 - 16x16 and 20x20")
     m = _model(shape, front, pol, val, 3)
     boards = _boards(n, shape, 5)
     with torch.no_grad():

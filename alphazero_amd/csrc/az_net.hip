@@ -1568,9 +1568,11 @@ int az_net_eval_masked(int shape, int n, const float *d_boards, const int *d_lea
     // Winograd form of the 3x3 layers from 12x12 on (fewer matrix instructions than the direct form there);
     // larger boards the Winograd kernel with one wavefront per SIMD (k_net_wide: measured faster than both
     // team kernels at every size from 16x16 to 20x20); 13x13 - 16x16, which are a 4x4 grid of 4x4 output
-    // tiles, and 20x20 (5x5 tiles, two wavefronts per position) the Winograd F(4x4,3x3) kernels
+    // tiles, and 19x19 / 20x20 (5x5 tiles, two wavefronts per position) the Winograd F(4x4,3x3) kernels
     // (az_net_w43.hip: per 8192 positions 0.29 ms at 13x13 - 15x15 against 0.36 - 0.38, 0.35 against 0.46 at
-    // 16x16, 0.64 against 0.85 at 20x20).  az_net_set_form overrides the choice.
+    // 16x16, 0.72 against 0.87 at 19x19, 0.64 against 0.85 at 20x20; at 17x17 and 18x18, where the masks of
+    // the overhanging tiles cost what the form saves, 0.73 / 0.71 against 0.73 / 0.70: k_net_wide stays).
+    // az_net_set_form overrides the choice.
     const int form = g_net_form.load(std::memory_order_relaxed);
     // A batch that leaves CUs idle (one tree behind the cmcts facade, a small arena) is bound by the latency of
     // one position, not by throughput: a team of wavefronts per position finishes it sooner than one wavefront
@@ -1585,7 +1587,7 @@ int az_net_eval_masked(int shape, int n, const float *d_boards, const int *d_lea
     const bool few = form == AZ_NET_FORM_AUTO && (n <= cus || (shape >= 16 && n <= 2 * cus));
     const bool team = form == AZ_NET_FORM_TEAM || few;
     const bool wino = form == AZ_NET_FORM_WINOGRAD || (form == AZ_NET_FORM_AUTO && shape >= 12);
-    if (((shape >= 13 && shape <= 16) || shape == 20) && (form == AZ_NET_FORM_W43 || (form == AZ_NET_FORM_AUTO && !few)))
+    if ((shape >= 13 && form == AZ_NET_FORM_W43) || (((shape >= 13 && shape <= 16) || shape >= 19) && form == AZ_NET_FORM_AUTO && !few))
         return az_net_w43_launch(shape, n, d_boards, d_leaf_kind, d_expand_mask, d_params, front_layers, policy_layers, value_layers,
                                  d_value, d_logp, st);
     switch (shape) {

@@ -480,16 +480,17 @@ template <int S> int launch_w43(const float *boards, const int *leaf_kind, const
 }
 
 // ---------------------------------------------------------------------------------
-// 20x20: a 5x5 grid of tiles = two blocks of 16 (seven dummies), a TEAM of two wavefronts per position, one block
+// 17x17 - 20x20: a 5x5 grid of tiles = two blocks of 16 (seven dummies), a TEAM of two wavefronts per position, one block
 // each (a board of that size fills 31 KB of LDS: four positions per CU, and two wavefronts per SIMD need eight
 // wavefronts).  Both wavefronts read their patches from the one buffer and write their outputs back into it, so a
 // barrier separates a layer's last patch read from its first store; the heads split the board rows.
 template <int S_> struct W43TeamGeo {
     using G = Geo<S_>;
-    static_assert(S_ == 20, "tiles that end on the board edge (patches end on the halo, no partial tiles)");
+    static_assert(S_ >= 17 && S_ <= 20, "a 5x5 grid of tiles");
+    static constexpr bool EXACT = S_ % 4 == 0; // the tiles end on the board edge: patches end on the halo, no partial tiles
     static constexpr int S = S_, SIZE = G::SIZE, ROW = G::ROW, PS = G::PS; // (what policy_softmax reads)
     static constexpr int NW = 2, NTHR = 128;
-    static constexpr int TW = S / 4, TILES = TW * TW;
+    static constexpr int TW = (S + 3) / 4, TILES = TW * TW;
     static constexpr unsigned DIV = 65536 / TW + 1; // T / TW == (T * DIV) >> 16 for T < 128
     static constexpr int TAIL = 64;
     static constexpr int LDS_BYTES = (G::BUF + TAIL + 16 + SIZE) * 4; // buffer, zero tail, reduction cells, logits
@@ -508,19 +509,33 @@ __device__ __forceinline__ void w43t_emit(float *buf, int co, unsigned T, float 
     using W = W43TeamGeo<S>;
     const bool valid = T < (unsigned)W::TILES;
     const unsigned ty = (T * W::DIV) >> 16, tx = T - ty * W::TW;
+    // (boards that the tile grid overhangs: cells outside the board are replaced by zero and folded onto the halo
+    // row below / the halo column right of the board, which stay zero that way)
+    const int rows_in = valid ? S - 4 * (int)ty : 0, cols_in = S - 4 * (int)tx;
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             const float v = __builtin_amdgcn_fmed3f(y[a][b], 0.f, INFINITY);
-            y[a][b] = valid ? v : 0.f;
+            if constexpr (W::EXACT) y[a][b] = valid ? v : 0.f;
+            else y[a][b] = (a < rows_in && b < cols_in) ? v : 0.f;
         }
     if (wr && valid) {
-        float *c = buf + co * G::PS + (int)((4 * ty + 1) * G::ROW + 4 * tx + 1);
+        if constexpr (W::EXACT) {
+            float *c = buf + co * G::PS + (int)((4 * ty + 1) * G::ROW + 4 * tx + 1);
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+            for (int a = 0; a < 4; a++)
 #pragma unroll
-            for (int b = 0; b < 4; b++) c[a * G::ROW + b] = y[a][b];
+                for (int b = 0; b < 4; b++) c[a * G::ROW + b] = y[a][b];
+        } else {
+            float *c = buf + co * G::PS + G::ROW + 1;
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                const int ra = (a < rows_in ? 4 * (int)ty + a : S) * G::ROW;
+#pragma unroll
+                for (int b = 0; b < 4; b++) c[ra + (b < cols_in ? 4 * (int)tx + b : S)] = y[a][b];
+            }
+        }
     }
     if (sum) {
 #pragma unroll
@@ -546,11 +561,22 @@ template <int S> __device__ __forceinline__ void w43t_restore(float *buf, int wa
         const unsigned T = (unsigned)(16 * wave + 4 * kq + r);
         const unsigned ty = (T * W::DIV) >> 16, tx = T - ty * W::TW;
         if (T < (unsigned)W::TILES) {
-            float *c = buf + co * G::PS + (int)((4 * ty + 1) * G::ROW + 4 * tx + 1);
+            if constexpr (W::EXACT) {
+                float *c = buf + co * G::PS + (int)((4 * ty + 1) * G::ROW + 4 * tx + 1);
 #pragma unroll
-            for (int a = 0; a < 4; a++)
+                for (int a = 0; a < 4; a++)
 #pragma unroll
-                for (int b = 0; b < 4; b++) c[a * G::ROW + b] = fc[fz + (a * 4 + b) * 4 + r];
+                    for (int b = 0; b < 4; b++) c[a * G::ROW + b] = fc[fz + (a * 4 + b) * 4 + r];
+            } else { // (cells outside the board were parked as zeros: folded onto the halo as in w43t_emit)
+                const int rows_in = S - 4 * (int)ty, cols_in = S - 4 * (int)tx;
+                float *c = buf + co * G::PS + G::ROW + 1;
+#pragma unroll
+                for (int a = 0; a < 4; a++) {
+                    const int ra = (a < rows_in ? 4 * (int)ty + a : S) * G::ROW;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) c[ra + (b < cols_in ? 4 * (int)tx + b : S)] = fc[fz + (a * 4 + b) * 4 + r];
+                }
+            }
         }
     }
 }
@@ -773,6 +799,15 @@ int az_net_w43_launch(int shape, int n, const float *d_boards, const int *d_leaf
     case 16:
         return launch_w43<16>(d_boards, d_leaf_kind, d_expand_mask, n, d_params, front_layers, policy_layers, value_layers, d_value,
                               d_logp, st);
+    case 17:
+        return launch_w43t<17>(d_boards, d_leaf_kind, d_expand_mask, n, d_params, front_layers, policy_layers, value_layers, d_value,
+                               d_logp, st);
+    case 18:
+        return launch_w43t<18>(d_boards, d_leaf_kind, d_expand_mask, n, d_params, front_layers, policy_layers, value_layers, d_value,
+                               d_logp, st);
+    case 19:
+        return launch_w43t<19>(d_boards, d_leaf_kind, d_expand_mask, n, d_params, front_layers, policy_layers, value_layers, d_value,
+                               d_logp, st);
     case 20:
         return launch_w43t<20>(d_boards, d_leaf_kind, d_expand_mask, n, d_params, front_layers, policy_layers, value_layers, d_value,
                                d_logp, st);

@@ -70,7 +70,7 @@ def net_kernel_of(shape):
     if 13 <= shape <= 16:  # Winograd F(4x4,3x3): one block of 16 tiles, 36 transformed positions, 4 K steps per layer
         return ("k_net_w43 (Winograd F(4x4,3x3), one wavefront per position)",
                 layers16 * 144 + 36 + shape * ((shape + 15) // 16) * 4)
-    if shape == 20:        # the same with two blocks (5x5 tiles), a team of two wavefronts per position
+    if shape >= 19:        # the same with two blocks (5x5 tiles), a team of two wavefronts per position
         return ("k_net_w43t (Winograd F(4x4,3x3), two wavefronts per position)",
                 layers16 * 288 + 72 + shape * ((shape + 15) // 16) * 4)
     if shape >= 16:   # Winograd F(2x2,3x3), tile grid of the board, blocks of 16 tiles, 16 transformed positions

@@ -323,13 +323,13 @@ int az_net_param_floats(int front_layers, int policy_layers, int value_layers);
  * tests that compare the forms): AUTO = the direct-form team kernel for batches of at most one
  * position per CU (two above 15x15), otherwise by board size (one wavefront per position and two
  * per SIMD up to 12x12, the 3x3 layers in the Winograd F(2x2,3x3) form at 12x12; the
- * Winograd F(4x4,3x3) kernels at 13x13 - 16x16 and 20x20; the F(2x2,3x3) kernel with one wavefront
- * per SIMD at 17x17 - 19x19); DIRECT / WINOGRAD = that form
+ * Winograd F(4x4,3x3) kernels at 13x13 - 16x16, 19x19 and 20x20; the F(2x2,3x3) kernel with one
+ * wavefront per SIMD at 17x17 and 18x18); DIRECT / WINOGRAD = that form
  * of the 3x3 layers for every size (one wavefront per position up to 15x15, a team of
  * four above; DIRECT above 15x15 is the same as TEAM); TEAM = the direct-form team kernel
  * for every size; WIDE = the one-wavefront-per-SIMD Winograd kernel from 12x12 on (AUTO's
  * choice below that); W43 = the Winograd F(4x4,3x3) kernels at 13x13 - 16x16 (one wavefront per
- * position) and 20x20 (two), AUTO's choice at the other sizes.  Process-wide; initial value from the environment
+ * position) and 17x17 - 20x20 (two), AUTO's choice below 13x13.  Process-wide; initial value from the environment
  * (AZ_NET_FORM). */
 enum { AZ_NET_FORM_AUTO = 0, AZ_NET_FORM_DIRECT = 1, AZ_NET_FORM_WINOGRAD = 2, AZ_NET_FORM_TEAM = 3, AZ_NET_FORM_WIDE = 4,
        AZ_NET_FORM_W43 = 5 };

@@ -36,7 +36,7 @@ def main():
                        cpuct=float(rng.choice([0.0, 0.5, 4.0, 10.0])), nodes=sims * 8 + 64, seed=int(rng.integers(1, 1000)))
         n_fused += 1
         if n_fused % 8 == 0:
-            B, S2 = int(rng.integers(2, 200)), int(rng.choice([5, 6, 7, 9, 13, 15, 16, 20]))
+            B, S2 = int(rng.integers(2, 200)), int(rng.choice([5, 6, 7, 9, 13, 14, 15, 16, 17, 19, 20]))
             TC.test_simulate_net_position_mask_with_idle_and_terminal_leaves(B, S2, int(rng.integers(2, 6)) if S2 != 5 else 24,
                                                                              bool(rng.integers(0, 2)))
             n_net += 1

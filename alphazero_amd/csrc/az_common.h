@@ -109,6 +109,10 @@ struct AzShapeOps {
                         float *d_board, void *stream);
     int (*dirichlet)(double *d_table, int rows, double alpha, unsigned long long seed, void *stream);
     int (*restart)(const AzParams &, const int *d_openings, int n_plies, int *d_count, void *stream);
+    // choose_moves with the record fields written to row d_ply[tree] of the tree's staging rows:
+    // d_stage + tree * max_plies * rec + d_ply[tree] * rec, rec = 3 * SIZE + 1 (board, pi, r)
+    int (*choose_moves_staged)(const AzParams &, const double *d_u, int *d_actions, float *d_stage, int max_plies,
+                               const int *d_ply, void *stream);
 };
 
 // Words of the expand masks are AZ_MASK_STRIDE words apart: the trees' atomic ORs then spread over four times

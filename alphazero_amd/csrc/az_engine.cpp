@@ -83,6 +83,10 @@ struct az_engine {
     std::vector<AzTree> h_trees;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> ev_slots; // [2 * slot + end] for az_timing_mark, created on first use
+    // one event per stream this engine has queued work on, re-recorded behind every asynchronous call: what the
+    // synchronous entry points wait for (instead of the whole device: other engines, torch and RCCL keep running)
+    struct StreamMark { hipStream_t stream; hipEvent_t done; };
+    std::vector<StreamMark> marks;
 };
 
 namespace {
@@ -132,6 +136,29 @@ int check_tree(const az_engine *e, int tree)
 {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     if (tree < 0 || tree >= e->n_trees) return fail(AZ_ERR_ARG, "tree index %d out of range (0-%d)", tree, e->n_trees - 1);
+    return AZ_OK;
+}
+
+// Called behind every asynchronous entry point: remembers that `stream` carries work of this engine.  A stream under
+// graph capture is left alone (an event recorded there belongs to the graph and cannot be waited for).
+void note_queued(az_engine *e, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (cap != hipStreamCaptureStatusNone) return;
+    for (auto &m : e->marks)
+        if (m.stream == st) { (void)hipEventRecord(m.done, st); return; }
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+    (void)hipEventRecord(ev, st);
+    e->marks.push_back({st, ev});
+}
+
+// waits for everything this engine has queued, on whatever stream
+int wait_queued(az_engine *e)
+{
+    for (auto &m : e->marks) HIP_TRY(hipEventSynchronize(m.done));
     return AZ_OK;
 }
 
@@ -252,7 +279,8 @@ void az_destroy(az_engine *e)
 {
     if (!e) return;
     DeviceGuard g(e->device);
-    (void)hipDeviceSynchronize();
+    (void)wait_queued(e);
+    (void)hipStreamSynchronize(nullptr);
     AzParams &P = e->P;
     void *ptrs[] = {P.nodes, P.parent, P.free_stack, P.order, P.trees, P.rows,
                     P.path_node, P.path_act, P.stamps, e->d_actions, e->d_mask, e->d_counts, e->d_root_n, e->d_noise, e->d_stage};
@@ -262,6 +290,7 @@ void az_destroy(az_engine *e)
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     for (hipEvent_t ev : e->ev_slots)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto &m : e->marks) (void)hipEventDestroy(m.done);
     delete e;
 }
 
@@ -322,7 +351,7 @@ int az_set_player(az_engine *e, int tree, int player)
     if (int rc = check_tree(e, tree)) return rc;
     if (player != 0 && player != 1) return fail(AZ_ERR_ARG, "player must be 0 or 1");
     DeviceGuard g(e->device);
-    HIP_TRY(hipDeviceSynchronize());
+    if (int rc_ = wait_queued(e)) return rc_;
     HIP_TRY(hipMemcpy((char *)(e->P.trees + tree) + offsetof(AzTree, player), &player, sizeof(int),
                       hipMemcpyHostToDevice));
     return AZ_OK;
@@ -332,7 +361,7 @@ int az_get_states(az_engine *e, int *player, int *move_cnt, float *winner)
 {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     DeviceGuard g(e->device);
-    HIP_TRY(hipDeviceSynchronize()); // work queued on any stream lands first
+    if (int rc_ = wait_queued(e)) return rc_; // work queued on any stream lands first
     if (int rc = fetch_trees(e)) return rc;
     for (int t = 0; t < e->n_trees; t++) {
         if (player) player[t] = e->h_trees[t].player;
@@ -346,7 +375,7 @@ int az_get_state(az_engine *e, int tree, int *player, int *move_cnt, float *winn
 {
     if (int rc = check_tree(e, tree)) return rc;
     DeviceGuard g(e->device);
-    HIP_TRY(hipDeviceSynchronize());
+    if (int rc_ = wait_queued(e)) return rc_;
     AzTree t;
     HIP_TRY(hipMemcpy(&t, e->P.trees + tree, sizeof t, hipMemcpyDeviceToHost));
     if (player) *player = t.player;
@@ -359,14 +388,14 @@ int az_clear_masked(az_engine *e, const unsigned char *mask)
 {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     DeviceGuard g(e->device);
-    HIP_TRY(hipDeviceSynchronize()); // searches queued on any stream finish before their trees are reset
+    if (int rc_ = wait_queued(e)) return rc_; // searches queued on any stream finish before their trees are reset
     if (mask) {
         HIP_TRY(hipMemcpy(e->d_mask, mask, e->n_trees, hipMemcpyHostToDevice));
         if (e->ops->clear(e->P, e->d_mask, nullptr)) return fail(AZ_ERR_HIP, "clear launch failed");
     } else {
         if (e->ops->clear(e->P, nullptr, nullptr)) return fail(AZ_ERR_HIP, "clear launch failed");
     }
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(nullptr));
     return AZ_OK;
 }
 
@@ -375,6 +404,7 @@ int az_make_move_greedy(az_engine *e, void *stream)
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     DeviceGuard g(e->device);
     if (e->ops->make_move(e->P, nullptr, stream)) return fail(AZ_ERR_HIP, "make_move launch failed");
+    note_queued(e, stream);
     return AZ_OK;
 }
 
@@ -383,6 +413,7 @@ int az_restart_finished(az_engine *e, const int *d_openings, int n_plies, int *d
     if (!e || n_plies < 0 || (n_plies > 0 && !d_openings)) return fail(AZ_ERR_ARG, "bad argument");
     DeviceGuard g(e->device);
     if (e->ops->restart(e->P, d_openings, n_plies, d_count, stream)) return fail(AZ_ERR_HIP, "restart launch failed");
+    note_queued(e, stream);
     return AZ_OK;
 }
 
@@ -400,7 +431,7 @@ int az_set_active(az_engine *e, const unsigned char *mask)
 {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     DeviceGuard g(e->device);
-    HIP_TRY(hipDeviceSynchronize());
+    if (int rc_ = wait_queued(e)) return rc_;
     if (int rc = fetch_trees(e)) return rc;
     for (int t = 0; t < e->n_trees; t++) e->h_trees[t].active = mask ? (mask[t] != 0) : 1;
     HIP_TRY(hipMemcpy(e->P.trees, e->h_trees.data(), sizeof(AzTree) * e->n_trees, hipMemcpyHostToDevice));
@@ -411,7 +442,7 @@ int az_set_noise_table(az_engine *e, const double *noise, int rows)
 {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     DeviceGuard g(e->device);
-    HIP_TRY(hipDeviceSynchronize());
+    if (int rc_ = wait_queued(e)) return rc_;
     if (e->d_noise) {
         (void)hipFree(e->d_noise);
         e->d_noise = nullptr;
@@ -465,6 +496,7 @@ int az_simulate_fused(az_engine *e, int n, int eval_kind, float const_prior, flo
     A.hash_seed = hash_seed;
     DeviceGuard g(e->device);
     if (e->ops->simulate_fused(e->P, A, stream)) return fail(AZ_ERR_HIP, "simulate launch failed");
+    note_queued(e, stream);
     return AZ_OK;
 }
 
@@ -476,6 +508,7 @@ int az_begin_simulate(az_engine *e, void *stream)
     // noise_row := 0 for every tree: a strided 4-byte memset
     HIP_TRY(hipMemset2DAsync((char *)e->P.trees + offsetof(AzTree, noise_row), sizeof(AzTree), 0, sizeof(int),
                              e->n_trees, (hipStream_t)stream));
+    note_queued(e, stream);
     return AZ_OK;
 }
 
@@ -484,6 +517,7 @@ int az_select(az_engine *e, float *d_boards, int *d_leaf_kind, void *stream)
     if (!e || !d_boards || !d_leaf_kind) return fail(AZ_ERR_ARG, "null argument");
     DeviceGuard g(e->device);
     if (e->ops->select(e->P, d_boards, d_leaf_kind, nullptr, nullptr, stream)) return fail(AZ_ERR_HIP, "select launch failed");
+    note_queued(e, stream);
     return AZ_OK;
 }
 
@@ -493,6 +527,7 @@ int az_expand_backup(az_engine *e, const float *d_value, const float *d_prior, i
     DeviceGuard g(e->device);
     if (e->ops->expand_backup(e->P, d_value, d_prior, prior_is_log, stream))
         return fail(AZ_ERR_HIP, "expand_backup launch failed");
+    note_queued(e, stream);
     return AZ_OK;
 }
 
@@ -590,7 +625,9 @@ int az_simulate_net(az_engine *e, int n, const float *d_params, int front_layers
         HIP_TRY(hipMalloc((void **)&e->d_stage, L.bytes));
         e->device_bytes += L.bytes;
     }
-    return simulate_net_steps(e, n, d_params, front_layers, policy_layers, value_layers, e->d_stage, stream);
+    const int rc = simulate_net_steps(e, n, d_params, front_layers, policy_layers, value_layers, e->d_stage, stream);
+    note_queued(e, stream);
+    return rc;
 }
 
 int az_simulate_net_noalloc(az_engine *e, int n, const float *d_params, int front_layers, int policy_layers,
@@ -613,7 +650,9 @@ int az_simulate_net_noalloc(az_engine *e, int n, const float *d_params, int fron
     DeviceGuard g(e->device);
     char *ptr = g_scratch_ptr[e->device]; // resolved by az_create on this device
     if (!ptr) return fail(AZ_ERR_STATE, "the fixed staging buffer was not resolved on device %d", e->device);
-    return simulate_net_steps(e, n, d_params, front_layers, policy_layers, value_layers, ptr, stream);
+    const int rc = simulate_net_steps(e, n, d_params, front_layers, policy_layers, value_layers, ptr, stream);
+    note_queued(e, stream);
+    return rc;
 }
 
 // Errors a kernel raises for a tree.  INVALID_MOVE and NOT_DIST leave the tree
@@ -690,6 +729,7 @@ int az_make_move(az_engine *e, const int *actions, int on_device, void *stream)
         d_act = e->d_actions;
     }
     if (e->ops->make_move(e->P, d_act, stream)) return fail(AZ_ERR_HIP, "make_move launch failed");
+    note_queued(e, stream);
     if (!on_device) {
         int tree = -1;
         int rc = sync_check_impl(e, stream, &tree);
@@ -720,6 +760,7 @@ int az_select_greedy(az_engine *e, int *d_actions, void *stream)
     if (!e || !d_actions) return fail(AZ_ERR_ARG, "null argument");
     DeviceGuard g(e->device);
     if (e->ops->select_greedy(e->P, d_actions, stream)) return fail(AZ_ERR_HIP, "select_greedy launch failed");
+    note_queued(e, stream);
     return AZ_OK;
 }
 
@@ -731,6 +772,7 @@ int az_choose_moves(az_engine *e, const double *d_u, int greedy, int *d_actions,
     DeviceGuard g(e->device);
     if (e->ops->choose_moves(e->P, d_u, greedy ? 1 : 0, d_actions, d_pi, d_board, stream))
         return fail(AZ_ERR_HIP, "choose_moves launch failed");
+    note_queued(e, stream);
     return AZ_OK;
 }
 
@@ -741,7 +783,7 @@ int az_fill_noise_dirichlet(az_engine *e, int rows, unsigned long long seed, voi
     if (!(e->alpha > 0.)) return fail(AZ_ERR_ARG, "alpha must be positive");
     DeviceGuard g(e->device);
     if (rows > e->noise_cap) {
-        HIP_TRY(hipDeviceSynchronize()); // searches in flight may still read the old table
+        if (int rc_ = wait_queued(e)) return rc_; // searches in flight may still read the old table
         if (e->d_noise) (void)hipFree(e->d_noise);
         e->d_noise = nullptr;
         e->noise_cap = 0;
@@ -753,6 +795,7 @@ int az_fill_noise_dirichlet(az_engine *e, int rows, unsigned long long seed, voi
     if (e->ops->dirichlet(e->d_noise, rows, e->alpha, seed, stream)) return fail(AZ_ERR_HIP, "dirichlet launch failed");
     e->P.noise = e->d_noise;
     e->P.noise_rows = rows;
+    note_queued(e, stream);
     return AZ_OK;
 }
 
@@ -761,7 +804,7 @@ int az_get_noise_table(az_engine *e, double *noise, int rows)
     if (!e || !noise) return fail(AZ_ERR_ARG, "null argument");
     if (rows < 0 || rows > e->P.noise_rows) return fail(AZ_ERR_ARG, "the table holds %d rows", e->P.noise_rows);
     DeviceGuard g(e->device);
-    HIP_TRY(hipDeviceSynchronize());
+    if (int rc_ = wait_queued(e)) return rc_;
     std::vector<double> padded((size_t)rows * e->sp);
     if (rows) HIP_TRY(hipMemcpy(padded.data(), e->d_noise, padded.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int r = 0; r < rows; r++)
@@ -773,7 +816,7 @@ int az_get_counts(az_engine *e, int *counts, int *root_n)
 {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     DeviceGuard g(e->device);
-    HIP_TRY(hipDeviceSynchronize());
+    if (int rc_ = wait_queued(e)) return rc_;
     if (e->ops->get_counts(e->P, e->d_counts, e->d_root_n, nullptr)) return fail(AZ_ERR_HIP, "get_counts launch failed");
     if (counts)
         HIP_TRY(hipMemcpy(counts, e->d_counts, sizeof(int) * (size_t)e->n_trees * e->size, hipMemcpyDeviceToHost));
@@ -800,7 +843,7 @@ int az_get_prob(az_engine *e, int tree, float *prob)
     if (int rc = check_tree(e, tree)) return rc;
     if (!prob) return fail(AZ_ERR_ARG, "null argument");
     DeviceGuard g(e->device);
-    HIP_TRY(hipDeviceSynchronize());
+    if (int rc_ = wait_queued(e)) return rc_;
     AzTree t;
     HIP_TRY(hipMemcpy(&t, e->P.trees + tree, sizeof t, hipMemcpyDeviceToHost));
     std::vector<int> n(e->sp, 0);
@@ -825,7 +868,7 @@ int az_get_raw_board(az_engine *e, int tree, signed char *board)
     if (int rc = check_tree(e, tree)) return rc;
     if (!board) return fail(AZ_ERR_ARG, "null argument");
     DeviceGuard g(e->device);
-    HIP_TRY(hipDeviceSynchronize());
+    if (int rc_ = wait_queued(e)) return rc_;
     unsigned rows[64];
     HIP_TRY(hipMemcpy(rows, e->P.rows + (size_t)tree * 64, sizeof rows, hipMemcpyDeviceToHost));
     const int S = e->shape;
@@ -839,7 +882,7 @@ int az_get_raw_boards(az_engine *e, signed char *boards)
 {
     if (!e || !boards) return fail(AZ_ERR_ARG, "null argument");
     DeviceGuard g(e->device);
-    HIP_TRY(hipDeviceSynchronize());
+    if (int rc_ = wait_queued(e)) return rc_;
     std::vector<unsigned> rows((size_t)e->n_trees * 64);
     HIP_TRY(hipMemcpy(rows.data(), e->P.rows, rows.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
     const int S = e->shape;
@@ -876,7 +919,7 @@ int az_get_node(az_engine *e, int tree, const int *path, int len, int *found, in
     if (int rc = check_tree(e, tree)) return rc;
     if (!found || (len > 0 && !path)) return fail(AZ_ERR_ARG, "null argument");
     DeviceGuard g(e->device);
-    HIP_TRY(hipDeviceSynchronize());
+    if (int rc_ = wait_queued(e)) return rc_;
     *found = 0;
     AzTree t;
     HIP_TRY(hipMemcpy(&t, e->P.trees + tree, sizeof t, hipMemcpyDeviceToHost));
@@ -913,7 +956,7 @@ int az_get_stats(az_engine *e, unsigned long long *sims, unsigned long long *exp
 {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     DeviceGuard g(e->device);
-    HIP_TRY(hipDeviceSynchronize());
+    if (int rc_ = wait_queued(e)) return rc_;
     if (int rc = fetch_trees(e)) return rc;
     unsigned long long s[4] = {0, 0, 0, 0};
     for (const auto &t : e->h_trees)
@@ -929,7 +972,7 @@ int az_reset_stats(az_engine *e)
 {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     DeviceGuard g(e->device);
-    HIP_TRY(hipDeviceSynchronize());
+    if (int rc_ = wait_queued(e)) return rc_;
     HIP_TRY(hipMemset2D((char *)e->P.trees + offsetof(AzTree, stats), sizeof(AzTree), 0, sizeof(unsigned long long) * 4,
                         e->n_trees));
     return AZ_OK;
@@ -939,7 +982,7 @@ int az_get_pool_usage(az_engine *e, int tree, int *used, int *max_used)
 {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     DeviceGuard g(e->device);
-    HIP_TRY(hipDeviceSynchronize());
+    if (int rc_ = wait_queued(e)) return rc_;
     if (int rc = fetch_trees(e)) return rc;
     if (used) {
         if (int rc = check_tree(e, tree)) return rc;
@@ -959,7 +1002,7 @@ int az_debug_stamps(az_engine *e, unsigned long long *out)
 {
     if (!e || !out) return fail(AZ_ERR_ARG, "null argument");
     DeviceGuard g(e->device);
-    HIP_TRY(hipDeviceSynchronize());
+    if (int rc_ = wait_queued(e)) return rc_;
     HIP_TRY(hipMemcpy(out, e->P.stamps, sizeof(unsigned long long) * 8 * e->n_trees, hipMemcpyDeviceToHost));
     return AZ_OK;
 }

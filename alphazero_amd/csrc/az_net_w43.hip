@@ -384,6 +384,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 buf[G::PS + ctr] = in1[i];
             }
         }
+        // 13x13 and 14x14: the patches of plane 1's last tile row reach rows 15..17, i.e. the first rows of plane 2,
+        // which is no input plane and still holds what the previous position left there.  Zeroed, so that a position's
+        // outputs never depend on what its workgroup evaluated before (sums that cancel only algebraically would
+        // otherwise carry a rounding residue of those leftovers into the last board row).
+        if constexpr (S < 15) {
+            static_assert(3 * G::ROW <= 64, "one cell per lane");
+            if (lane < 3 * G::ROW) buf[2 * G::PS + lane] = 0.f;
+        }
         __syncthreads();
         NST(0);
         float vsum = 0.f;
@@ -445,7 +453,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (lane + 64 * i < G::SIZE) logp_out[(size_t)pos * G::SIZE + lane + 64 * i] = logit[i] - lse;
         __syncthreads(); // the gather is over before the next position's input lands in the buffer
         NST(3);
-        // planes 2..15 keep leftovers (partial planes, old activations): the input layer reads planes 0..1 only
+        // planes 2..15 keep leftovers (partial planes, old activations): the input layer reads planes 0..1 (and, on boards
+        // the tile grid overhangs, the first rows of plane 2, zeroed above)
     }
 #ifdef AZ_NET_STAMPS
     if (lane == 0 && n_mine > 0 && leaf_kind == nullptr) { // diagnostic build: cycle sums over the log-priors of the first position
@@ -718,6 +727,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 buf[ctr] = in0[i];
                 buf[G::PS + ctr] = in1[i];
             }
+        }
+        // 17x17 and 18x18: the patches of plane 1's last tile row reach rows 19..21, the first rows of plane 2, which
+        // still holds the previous position's leftovers: zeroed, so that the outputs depend on the position alone
+        if constexpr (S < 19) {
+            static_assert(3 * G::ROW <= W::NTHR, "one cell per thread");
+            if (tid < 3 * G::ROW) buf[2 * G::PS + tid] = 0.f;
         }
         __syncthreads();
         float vsum = 0.f;

@@ -8,8 +8,10 @@
  * `stream` arguments are a hipStream_t passed as void* (NULL = default stream).
  * Entry points WITHOUT a stream argument that touch device state (setters of
  * per-tree state, az_clear*, the az_get_* read-backs) first wait for all work
- * queued on the device (hipDeviceSynchronize), so they are ordered after
- * searches and moves issued on any stream.
+ * THIS ENGINE has queued, on whatever streams (an event per stream, recorded
+ * behind every asynchronous call), so they are ordered after its searches and
+ * moves; work of other engines, of the caller or of a collective library on
+ * the same GPU is not waited for.
  *
  * Each function cites the reference interface it replaces
  * (paths relative to the reference repository root).
@@ -269,6 +271,59 @@ int az_get_errors(az_engine *e, void *stream, int *codes);
  * caller does after every move (`mcts.winner != -1`, src/self_play.py:169,185;
  * src/eval.py:194,204).  Any of the three output arrays may be NULL. */
 int az_sync_states(az_engine *e, void *stream, int *player, int *move_cnt, float *winner);
+
+/* ---- game loops without a host round trip per move.
+ * The reference's callers decide between two moves, on the host, whether the game is
+ * over, who moves next and when the next game starts (src/self_play.py:86-117 around
+ * self_play_game :155-186; src/eval.py:111-149 around eval_game :187-209).  The entry
+ * points below keep those decisions in device arrays the caller owns, so a half-move is
+ * a fixed sequence of asynchronous calls on one stream and the host only polls the
+ * counters, as late as it likes:
+ *   d_game_of  int32 [n_trees]  game played in each tree slot, -1 = idle (start: all -1)
+ *   d_ply      int32 [n_trees]  half-moves that game has played
+ *   d_counters int32 [AZ_SLOT_COUNTERS], start: all 0 (indices AZ_SLOT_*)
+ * Engines `a` and `b` hold the two trees of every game (mcts0 / mcts1, or the two
+ * networks' trees), slot t of both = the same game; b may be NULL (one tree per game).
+ * All of them are asynchronous on `stream`. */
+enum {
+    AZ_SLOT_NEXT_GAME = 0, /* index the next admitted game gets                             */
+    AZ_SLOT_FINISHED = 1,  /* games finished so far                                         */
+    AZ_SLOT_RECORDS = 2,   /* records emitted to the arena so far                           */
+    AZ_SLOT_ERRORS = 3,    /* trees in error at the last az_slots_finish (their games stall) */
+    AZ_SLOT_ARENA_FULL = 4,/* set when a finished game's records did not fit the arena      */
+    AZ_SLOT_HALF_MOVES = 5,/* az_slots_finish calls so far                                  */
+    AZ_SLOT_COUNTERS = 8
+};
+/* Loop head (src/self_play.py:86-91, src/eval.py:111-116): every idle slot, in slot order,
+ * takes the next game while fewer than n_games have been started: Cmcts::clear on its
+ * tree(s), then the opening moves `openings[0..n_open)` (host array; tools.make_init_moves,
+ * src/tools.py:41-44), ply = 0, trees active. */
+int az_slots_admit(az_engine *a, az_engine *b, int *d_game_of, int *d_ply, int *d_counters, int n_games,
+                   const int *openings, int n_open, void *stream);
+/* Which trees of `e` search next: the live slots whose (ply + game * by_game) has the given
+ * parity (the arena's networks take turns opening, src/eval.py:117,134; mcts0 searches the
+ * even half-moves, src/self_play.py:156,172); parity < 0: every live slot. */
+int az_slots_turn(az_engine *e, const int *d_game_of, const int *d_ply, int by_game, int parity, void *stream);
+/* az_choose_moves for the games in the slots: the sampling limit is the game's own pair
+ * index (ply / 2 <= tau samples, src/self_play.py:159-164), the uniform number of a
+ * sampled move is a hash of (seed, game, ply) -- mix64(mix64(seed ^ (game << 32 | ply)) +
+ * 0x9e3779b97f4a7c15), top 53 bits + 0.5, over 2^53, mix64 = the splitmix64 finaliser -- so
+ * a game's moves do not depend on the slot it is played in; tau < 0: always the first
+ * maximum (the arena, src/eval.py:192).  d_stage (may be NULL): float [n_trees][max_plies][rec],
+ * rec = 3 * SIZE + 1: the record of the move (board, pi; r is filled at the end of the
+ * game) is written to row `ply` of the slot.  The moves go to d_actions, not applied. */
+int az_slots_choose(az_engine *e, const int *d_game_of, const int *d_ply, int tau, unsigned long long seed,
+                    int *d_actions, float *d_stage, int max_plies, void *stream);
+/* After the move has been applied to both engines (az_make_move): slots whose game is over
+ * (State::winner of a's tree != -1; src/self_play.py:169,185) write d_outcome[game] (float
+ * [n_games]) and go idle, the others count the half-move.  With d_stage / d_arena (float
+ * [arena_records][rec]) the finished games' records move to the arena as one block per game,
+ * mcts0's records first, labelled as src/self_play.py:188-200 (1 / -1 by winner, 1e-3 for a
+ * draw); d_game_off / d_game_len (int32 [n_games]) receive the block's first record and
+ * length.  Blocks are laid out in the order games finish (slot order inside a half-move). */
+int az_slots_finish(az_engine *a, az_engine *b, int *d_game_of, int *d_ply, int *d_counters, float *d_outcome,
+                    const float *d_stage, int max_plies, float *d_arena, long long arena_records, int *d_game_off,
+                    int *d_game_len, void *stream);
 
 /* HIP-event timing of the engine's own kernels on the stream they were
  * launched on: az_timing_begin records, az_timing_end records + waits and

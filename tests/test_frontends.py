@@ -26,7 +26,7 @@ def test_best_pointer_round_trip(tmp_path, monkeypatch):
     assert json.load(open(book.pointer_file)) == {"path": str(params / "simplerNN13_0002.pyt")}
     book.set_best("simplerNN13_0001.pyt")  # a bare name is looked up inside the parameter directory
     assert book.get_best() == str(params / "simplerNN13_0001.pyt")
-    with pytest.raises(RuntimeError, match="does not exst"):
+    with pytest.raises(RuntimeError, match="does not exist"):
         book.set_best("simplerNN13_0404.pyt")
     # a recorded file that moved: same name inside the parameter directory
     with open(book.pointer_file, "w") as f:

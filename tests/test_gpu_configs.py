@@ -91,7 +91,7 @@ def test_simulate_net_equals_the_three_step_path(S, threads):
 
 @pytest.mark.parametrize("one_launch", [False, True])
 @pytest.mark.parametrize("B,S,plies", [(77, 5, 24), (130, 7, 3), (33, 16, 3), (41, 15, 2), (21, 20, 2), (29, 13, 2), (18, 19, 2)])
-def test_simulate_net_position_mask_with_idle_and_terminal_leaves(B, S, plies, one_launch):
+def test_simulate_net_position_mask_with_idle_and_terminal_leaves(B, S, plies, one_launch, net_form):
     """az_simulate_net tells its evaluator which positions to evaluate through the bit mask az_select
     fills (the three-step path scans the leaf codes): tree counts that are no multiple of 32, idle trees
     and, on small boards, searches that end on finished games; every statistic stays bit-identical.
@@ -104,7 +104,7 @@ def test_simulate_net_position_mask_with_idle_and_terminal_leaves(B, S, plies, o
     _, ev = _fused(S, seed=5)
     # the one-wavefront kernels are the ones that read the mask; batches this small would get the team kernel
     if not one_launch:
-        assert ev.L.az_net_set_form({13: 5, 14: 5, 15: 5, 16: 4, 17: 5, 18: 4, 19: 5, 20: 5}.get(S, 2)) == 0  # AZ_NET_FORM_W43 / AZ_NET_FORM_WIDE / AZ_NET_FORM_WINOGRAD
+        net_form({13: "w43", 14: "w43", 15: "w43", 16: "wide", 17: "w43", 18: "wide", 19: "w43", 20: "w43"}.get(S, "winograd"))
     active = (np.arange(B) % 5 != 2).astype(np.uint8)
     engs = []
     for _ in range(2):
@@ -141,7 +141,6 @@ def test_simulate_net_position_mask_with_idle_and_terminal_leaves(B, S, plies, o
         active = (active.astype(bool) & (a.get_states()[2] == -1.0)).astype(np.uint8)
         for eng in (a, b):
             eng.set_active(active)
-    ev.L.az_net_set_form(0)
     if S == 5:
         assert terminals > 0 and not active.any()  # searches reached finished games; every game is over
     a.close()

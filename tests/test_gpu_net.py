@@ -34,23 +34,6 @@ def _boards(n, shape, seed):
     return b.reshape(n, 2, shape, shape)
 
 
-FORMS = {"auto": 0, "direct": 1, "winograd": 2, "team": 3, "wide": 4, "w43": 5}  # AZ_NET_FORM_* of include/azmcts.h
-
-
-@pytest.fixture
-def net_form():
-    """Selects the kernel az_net_eval runs for the duration of a test."""
-    from alphazero_amd import engine as E
-
-    lib = E.load_library()
-
-    def choose(name):
-        assert lib.az_net_set_form(FORMS[name]) == 0
-
-    yield choose
-    lib.az_net_set_form(FORMS["auto"])
-
-
 @pytest.mark.parametrize("form", ["auto", "direct", "winograd", "team", "wide", "w43"])
 @pytest.mark.parametrize("shape,front,pol,val,n", [(15, 4, 2, 2, 300), (13, 4, 2, 2, 50), (20, 3, 1, 2, 40),
                                                      (7, 1, 0, 0, 9), (5, 2, 3, 1, 1100), (14, 2, 0, 1, 70),
@@ -152,3 +135,32 @@ def test_fused_net_skips_leaves_that_need_no_evaluation():
     assert np.array_equal(value[need], v_all.cpu().numpy()[need])
     assert np.array_equal(logp[need], lp_all.cpu().numpy()[need])
     assert np.all(value[~need] == 7.0) and np.all(logp[~need] == 7.0)
+
+
+@pytest.mark.parametrize("shape,form", [(13, "auto"), (14, "auto"), (17, "w43"), (18, "w43"), (15, "auto"), (20, "auto")])
+def test_outputs_do_not_depend_on_the_batch_slot(shape, form, net_form):
+    """A position's value and log-probabilities are a function of the position alone: the same
+    board placed in several slots of a batch larger than the launch grid (so that workgroups
+    evaluate it after different predecessors, on buffers holding different leftovers) gives
+    bit-identical outputs.  Covers the boards whose tile grid overhangs the board (13, 14, 17,
+    18), where the input layer's patches reach past the two input planes."""
+    import torch
+    from alphazero_amd.evaluator import FusedNetEvaluator
+
+    n = 2048 * 3 + 77  # more than eight positions per CU on 256 CUs, several rounds per workgroup
+    m = _model(shape, 4, 2, 2, 11)
+    boards = _boards(n, shape, 13)
+    probe = boards[5].copy()
+    slots = [0, 1, 63, 2047, 2048, 2049, 3000, 4095, 4096, 5000, n - 2, n - 1]
+    boards[slots] = probe
+    ev = FusedNetEvaluator(m.float(), shape)
+    net_form(form)
+    v, lp = ev(torch.from_numpy(boards).cuda())
+    v, lp = v.cpu().numpy(), lp.cpu().numpy()
+    for s in slots[1:]:
+        assert v[s] == v[slots[0]], s
+        assert np.array_equal(lp[s], lp[slots[0]]), s
+    # and the same position as every workgroup's first, on freshly zeroed buffers
+    net_form("w43" if shape >= 13 and form == "auto" else form)  # (a batch of one would get the latency kernel)
+    v1, lp1 = ev(torch.from_numpy(np.repeat(probe[None], 300, axis=0)).cuda())
+    assert v1.cpu().numpy()[0] == v[slots[0]] and np.array_equal(lp1.cpu().numpy()[0], lp[slots[0]])

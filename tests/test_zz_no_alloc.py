@@ -1,8 +1,9 @@
 """az_simulate_net_noalloc (the allocation-free variant of az_simulate_net, step staging
 in the library's fixed per-GPU buffer) against az_simulate_net, through the C ABI:
 bit-identical statistics on two calls in a row, the second with a smaller input
-(it runs on top of what the first call left in the buffer), and a clear error
-beyond the buffer's size."""
+(more trees than the GPU has CUs, so it too takes the stepped path and lays its
+smaller staging layout over what the first call left in the buffer), no change in
+the device's free memory across the calls, and a clear error beyond the buffer's size."""
 import numpy as np
 import pytest
 
@@ -46,12 +47,21 @@ def test_noalloc_entry_point_equals_az_simulate_net():
     for S in (15, 9):
         torch.manual_seed(S)
         evs[S] = FusedNetEvaluator(PolicyValueNet(S).eval(), S, 0)
-    # first call: 600 trees of 15x15; second: 70 trees of 9x9 over the first call's leftovers
-    for B, S, sims, seed in ((600, 15, 40, 1), (70, 9, 30, 2)):
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    # first call: 600 trees of 15x15; second: 300 trees of 9x9 over the first call's leftovers.  Both batches hold
+    # more trees than the GPU has CUs: a batch of at most one tree per CU would run as one launch that stages in LDS.
+    for B, S, sims, seed in ((600, 15, 40, 1), (300, 9, 30, 2)):
+        assert B > cus
         ev = evs[S]
         fixed, ref = _pair(E, B, S, sims, seed)
         for ply in range(2):
+            torch.cuda.synchronize()
+            held, free_before = fixed.device_bytes(), torch.cuda.mem_get_info(0)[0]
             fixed.simulate_net_noalloc(sims, ev.params.data_ptr(), ev.fused_layers, stream)
+            torch.cuda.synchronize()
+            assert fixed.device_bytes() == held  # the engine allocated nothing ...
+            if ply > 0:  # ... and neither did anything below it (the first ply loads the kernels' code)
+                assert torch.cuda.mem_get_info(0)[0] == free_before
             ref.simulate_net(sims, ev.params.data_ptr(), ev.fused_layers, stream)
             counts = _same(fixed, ref)
             act = counts.argmax(axis=1).astype(np.int32)

@@ -80,6 +80,8 @@ struct az_engine {
     double *d_noise = nullptr;     // [rows][sp]
     int noise_cap = 0;             // rows allocated at d_noise
     char *d_stage = nullptr;       // az_simulate_net: leaf boards, codes, values, log-priors of one step
+    double *d_u = nullptr;         // [n_trees] az_slots_choose: the uniform number of each slot's move
+    int *d_emit = nullptr;         // [3][n_trees] az_slots_finish: first record, record count and game of the slots that finish
     std::vector<AzTree> h_trees;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> ev_slots; // [2 * slot + end] for az_timing_mark, created on first use
@@ -170,6 +172,7 @@ const char *kernel_err_text(int code)
     case AZ_ERR_NOISE_ROWS: return "noise table exhausted";
     case AZ_ERR_INVALID_MOVE: return "Invalid move";
     case AZ_ERR_NOT_DIST: return "Not a distribution";
+    case AZ_ERR_STATE: return "record row outside the staging rows";
     default: return "kernel error";
     }
 }
@@ -241,6 +244,8 @@ int az_create(az_engine **out, int device, int n_trees, int shape, int nodes_per
     if (!rc) rc = dev_alloc(e, &e->d_mask, (size_t)n_trees);
     if (!rc) rc = dev_alloc(e, &e->d_counts, (size_t)n_trees * e->size);
     if (!rc) rc = dev_alloc(e, &e->d_root_n, (size_t)n_trees);
+    if (!rc) rc = dev_alloc(e, &e->d_u, (size_t)n_trees);
+    if (!rc) rc = dev_alloc(e, &e->d_emit, (size_t)3 * n_trees);
 #ifdef AZ_STAMPS
     if (!rc) rc = dev_alloc(e, &P.stamps, (size_t)n_trees * 8);
 #endif
@@ -283,7 +288,8 @@ void az_destroy(az_engine *e)
     (void)hipStreamSynchronize(nullptr);
     AzParams &P = e->P;
     void *ptrs[] = {P.nodes, P.parent, P.free_stack, P.order, P.trees, P.rows,
-                    P.path_node, P.path_act, P.stamps, e->d_actions, e->d_mask, e->d_counts, e->d_root_n, e->d_noise, e->d_stage};
+                    P.path_node, P.path_act, P.stamps, e->d_actions, e->d_mask, e->d_counts, e->d_root_n, e->d_noise, e->d_stage,
+                    e->d_u, e->d_emit};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -993,6 +999,88 @@ int az_get_pool_usage(az_engine *e, int tree, int *used, int *max_used)
         for (const auto &t : e->h_trees) m = t.n_order > m ? t.n_order : m;
         *max_used = m;
     }
+    return AZ_OK;
+}
+
+// ---- device-resident game loops (az_slots.hip)
+static int check_pair(const az_engine *a, const az_engine *b)
+{
+    if (!a) return fail(AZ_ERR_ARG, "null engine");
+    if (b && (b->n_trees != a->n_trees || b->shape != a->shape || b->device != a->device))
+        return fail(AZ_ERR_ARG, "the two engines of a game loop must agree in trees, board and device");
+    return AZ_OK;
+}
+
+int az_slots_admit(az_engine *a, az_engine *b, int *d_game_of, int *d_ply, int *d_counters, int n_games, const int *openings,
+                   int n_open, void *stream)
+{
+    if (int rc = check_pair(a, b)) return rc;
+    if (!d_game_of || !d_ply || !d_counters || n_games < 0 || n_open < 0 || (n_open > 0 && !openings))
+        return fail(AZ_ERR_ARG, "bad argument");
+    DeviceGuard g(a->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (az_slots_launch_admit(a->P.trees, b ? b->P.trees : nullptr, a->n_trees, d_game_of, d_ply, d_counters, n_games, a->d_mask, st))
+        return fail(AZ_ERR_HIP, "admit launch failed");
+    if (a->ops->clear(a->P, a->d_mask, stream)) return fail(AZ_ERR_HIP, "clear launch failed");
+    if (b && b->ops->clear(b->P, a->d_mask, stream)) return fail(AZ_ERR_HIP, "clear launch failed");
+    for (int k = 0; k < n_open; k++) { // the same opening for every game (tools.make_init_moves)
+        if (openings[k] < 0 || openings[k] >= a->size) return fail(AZ_ERR_INVALID_MOVE, "Invalid move %d (opening)", openings[k]);
+        if (az_slots_launch_fill_actions(a->d_mask, a->n_trees, openings[k], a->d_actions, st))
+            return fail(AZ_ERR_HIP, "opening launch failed");
+        if (a->ops->make_move(a->P, a->d_actions, stream)) return fail(AZ_ERR_HIP, "make_move launch failed");
+        if (b && b->ops->make_move(b->P, a->d_actions, stream)) return fail(AZ_ERR_HIP, "make_move launch failed");
+    }
+    note_queued(a, stream);
+    if (b) note_queued(b, stream);
+    return AZ_OK;
+}
+
+int az_slots_turn(az_engine *e, const int *d_game_of, const int *d_ply, int by_game, int parity, void *stream)
+{
+    if (!e || !d_game_of || !d_ply) return fail(AZ_ERR_ARG, "null argument");
+    DeviceGuard g(e->device);
+    if (az_slots_launch_turn(e->P.trees, e->n_trees, d_game_of, d_ply, by_game ? 1 : 0, parity < 0 ? -1 : (parity & 1),
+                             (hipStream_t)stream))
+        return fail(AZ_ERR_HIP, "turn launch failed");
+    note_queued(e, stream);
+    return AZ_OK;
+}
+
+int az_slots_choose(az_engine *e, const int *d_game_of, const int *d_ply, int tau, unsigned long long seed, int *d_actions,
+                    float *d_stage, int max_plies, void *stream)
+{
+    if (!e || !d_game_of || !d_ply || !d_actions) return fail(AZ_ERR_ARG, "null argument");
+    if (d_stage && max_plies < 1) return fail(AZ_ERR_ARG, "max_plies must be at least 1");
+    DeviceGuard g(e->device);
+    if (az_slots_launch_uniform(d_game_of, d_ply, e->n_trees, tau, seed, e->d_u, (hipStream_t)stream))
+        return fail(AZ_ERR_HIP, "uniform launch failed");
+    if (e->ops->choose_moves_staged(e->P, e->d_u, d_actions, d_stage, max_plies, d_ply, stream))
+        return fail(AZ_ERR_HIP, "choose_moves launch failed");
+    note_queued(e, stream);
+    return AZ_OK;
+}
+
+int az_slots_finish(az_engine *a, az_engine *b, int *d_game_of, int *d_ply, int *d_counters, float *d_outcome, const float *d_stage,
+                    int max_plies, float *d_arena, long long arena_records, int *d_game_off, int *d_game_len, void *stream)
+{
+    if (int rc = check_pair(a, b)) return rc;
+    if (!d_game_of || !d_ply || !d_counters || !d_outcome) return fail(AZ_ERR_ARG, "null argument");
+    const bool rec = d_stage != nullptr;
+    if (rec && (!d_arena || !d_game_off || !d_game_len || max_plies < 1 || arena_records < 0 || arena_records > 0x7fffffffll))
+        return fail(AZ_ERR_ARG, "records need an arena (at most 2^31-1 records), the two directory arrays and max_plies");
+    DeviceGuard g(a->device);
+    hipStream_t st = (hipStream_t)stream;
+    int *eo = a->d_emit, *en = a->d_emit + a->n_trees, *eg = a->d_emit + 2 * (size_t)a->n_trees;
+    if (az_slots_launch_finish(a->P.trees, b ? b->P.trees : nullptr, a->n_trees, d_game_of, d_ply, d_counters, d_outcome, rec ? 1 : 0,
+                               arena_records, d_game_off, d_game_len, eo, en, eg, st))
+        return fail(AZ_ERR_HIP, "finish launch failed");
+    if (rec) {
+        const int recf = 3 * a->size + 1;
+        if (az_slots_launch_emit(d_stage, (long long)max_plies * recf, recf, a->n_trees, eo, en, eg, d_outcome, d_arena, st))
+            return fail(AZ_ERR_HIP, "emit launch failed");
+    }
+    note_queued(a, stream);
+    if (b) note_queued(b, stream);
     return AZ_OK;
 }
 

@@ -1563,8 +1563,10 @@ __global__ __launch_bounds__(64) void k_get_counts(AzParams P, int *d_counts, in
 //   board = State::get_board (mcts/src/state.cpp:39-48): plane 0 = side to move.
 // The two running sums are sequential on purpose (one lane): their rounding is
 // part of the result.
+// d_ply (may be null): the record fields go to row d_ply[tree] of the tree's staging rows instead of dense
+// arrays: d_board = the staging base, float [n_trees][max_plies][3 * SIZE + 1] (board, pi, r), d_pi unused.
 __global__ __launch_bounds__(64) void k_choose_moves(AzParams P, const double *d_u, int greedy, int *d_actions,
-                                                     float *d_pi, float *d_board)
+                                                     float *d_pi, float *d_board, const int *d_ply, int max_plies)
 {
     constexpr int E = EPL;
     const int tree = blockIdx.x;
@@ -1631,19 +1633,31 @@ __global__ __launch_bounds__(64) void k_choose_moves(AzParams P, const double *d
         move = cnt < SIZE ? cnt : SIZE - 1;
     }
     if (lane == 0) d_actions[tree] = move;
-    if (d_pi != nullptr) {
+    float *pi_out = d_pi != nullptr ? d_pi + (size_t)tree * SIZE : nullptr;
+    float *board_out = d_board != nullptr ? d_board + (size_t)tree * 2 * SIZE : nullptr;
+    if (d_ply != nullptr) {
+        constexpr int REC = 3 * SIZE + 1;
+        const int row = uni(d_ply[tree]);
+        if (row < 0 || row >= max_plies) { // (cannot happen for a game of at most SIZE moves: refuse rather than write outside)
+            if (lane == 0) { T->err = AZ_ERR_STATE; d_actions[tree] = -1; }
+            return;
+        }
+        board_out = d_board + ((size_t)tree * max_plies + row) * REC;
+        pi_out = board_out + 2 * SIZE;
+    }
+    if (pi_out != nullptr) {
 #pragma unroll
         for (int k = 0; k < E; k++) {
             const int a = lane * E + k;
-            if (a < SIZE) d_pi[(size_t)tree * SIZE + a] = greedy ? (a == move ? 1.f : 0.f) : pi[k];
+            if (a < SIZE) pi_out[a] = greedy ? (a == move ? 1.f : 0.f) : pi[k];
         }
     }
-    if (d_board != nullptr) {
+    if (board_out != nullptr) {
         const unsigned rb = P.rows[tree * 64 + lane];
         const int row = lane & 31, plane = lane >> 5;
         const int out_plane = uni(T->player) == 1 ? 1 - plane : plane;
         if (row < S) {
-            float *dst = d_board + (size_t)tree * 2 * SIZE + out_plane * SIZE + row * S;
+            float *dst = board_out + out_plane * SIZE + row * S;
 #pragma unroll
             for (int c = 0; c < S; c++) dst[c] = (float)((rb >> c) & 1u);
         }
@@ -1816,7 +1830,14 @@ int l_choose_moves(const AzParams &P, const double *d_u, int greedy, int *d_acti
                    void *stream)
 {
     hipLaunchKernelGGL(k_choose_moves, dim3(P.n_trees), dim3(64), 0, (hipStream_t)stream, P, d_u, greedy, d_actions,
-                       d_pi, d_board);
+                       d_pi, d_board, nullptr, 0);
+    return launch_status();
+}
+int l_choose_moves_staged(const AzParams &P, const double *d_u, int *d_actions, float *d_stage, int max_plies, const int *d_ply,
+                          void *stream)
+{
+    hipLaunchKernelGGL(k_choose_moves, dim3(P.n_trees), dim3(64), 0, (hipStream_t)stream, P, d_u, 0, d_actions, nullptr, d_stage,
+                       d_stage != nullptr ? d_ply : nullptr, max_plies);
     return launch_status();
 }
 int l_dirichlet(double *d_table, int rows, double alpha, unsigned long long seed, void *stream)
@@ -1836,7 +1857,7 @@ extern "C" const AzShapeOps *AZ_CAT(az_shape_ops_, AZ_S)(void)
 {
     static const AzShapeOps ops = {
         AZ_S, SP, l_simulate_fused, l_select, l_expand_backup, l_backup_select, l_net_search, l_make_move, l_clear, l_select_greedy, l_get_counts,
-        l_choose_moves, l_dirichlet, l_restart,
+        l_choose_moves, l_dirichlet, l_restart, l_choose_moves_staged,
     };
     return &ops;
 }

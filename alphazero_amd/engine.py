@@ -83,6 +83,10 @@ SYMBOLS = [
     ("az_sync_states", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("az_make_move_greedy", _i, [_vp, _vp]),
     ("az_restart_finished", _i, [_vp, _vp, _i, _vp, _vp]),
+    ("az_slots_admit", _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    ("az_slots_turn", _i, [_vp, _vp, _vp, _i, _i, _vp]),
+    ("az_slots_choose", _i, [_vp, _vp, _vp, _i, _ull, _vp, _vp, _i, _vp]),
+    ("az_slots_finish", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, C.c_longlong, _vp, _vp, _vp]),
     ("az_timing_mark", _i, [_vp, _i, _i, _vp]),
     ("az_timing_elapsed", _i, [_vp, _i, C.POINTER(_f)]),
     ("az_timing_begin", _i, [_vp, _vp]),
@@ -357,6 +361,27 @@ class Engine:
         """clear + opening moves for every finished game, on the GPU (device pointers)."""
         self._check(self.L.az_restart_finished(self.h, _ptr(d_openings) if n_plies else None, int(n_plies),
                                                _ptr(d_count) if d_count is not None else None, stream))
+
+    # ---- device-resident game loops (slot bookkeeping in device arrays; everything asynchronous)
+    def slots_admit(self, other, d_game_of, d_ply, d_counters, n_games, openings=(), stream=None):
+        op = np.ascontiguousarray(openings, np.int32)
+        self._check(self.L.az_slots_admit(self.h, other.h if other is not None else None, _ptr(d_game_of), _ptr(d_ply),
+                                          _ptr(d_counters), int(n_games), _ptr(op) if op.size else None, int(op.size), stream))
+
+    def slots_turn(self, d_game_of, d_ply, by_game, parity, stream=None):
+        self._check(self.L.az_slots_turn(self.h, _ptr(d_game_of), _ptr(d_ply), int(bool(by_game)), int(parity), stream))
+
+    def slots_choose(self, d_game_of, d_ply, tau, seed, d_actions, d_stage=None, max_plies=0, stream=None):
+        self._check(self.L.az_slots_choose(self.h, _ptr(d_game_of), _ptr(d_ply), int(tau), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                           _ptr(d_actions), _ptr(d_stage) if d_stage is not None else None, int(max_plies),
+                                           stream))
+
+    def slots_finish(self, other, d_game_of, d_ply, d_counters, d_outcome, d_stage=None, max_plies=0, d_arena=None,
+                     arena_records=0, d_game_off=None, d_game_len=None, stream=None):
+        opt = lambda x: _ptr(x) if x is not None else None
+        self._check(self.L.az_slots_finish(self.h, other.h if other is not None else None, _ptr(d_game_of), _ptr(d_ply),
+                                           _ptr(d_counters), _ptr(d_outcome), opt(d_stage), int(max_plies), opt(d_arena),
+                                           int(arena_records), opt(d_game_off), opt(d_game_len), stream))
 
     def timing_mark(self, slot, end, stream=None):
         self._check(self.L.az_timing_mark(self.h, int(slot), int(bool(end)), stream))

@@ -66,8 +66,17 @@ class TreeBatch:
         evaluator call per search step."""
         if n < 1:
             raise RuntimeError(f"Invalid input {n} must be at least 1!")
+        self.eng.set_active(None if active is None else np.asarray(active, np.uint8))
+        self.queue_simulate(n)
+        try:
+            self.eng.sync_check(self.torch.cuda.current_stream(self.dev).cuda_stream)
+        except _E.EngineError as e:
+            raise RuntimeError(str(e)) from None
+
+    def queue_simulate(self, n):
+        """simulate(n) on the trees whose active flag is set, queued on the current stream:
+        no host wait, errors surface at the next sync_check."""
         eng, torch = self.eng, self.torch
-        eng.set_active(None if active is None else np.asarray(active, np.uint8))
         th_num, per = 1, n
         threads = eng.get_threads()
         if threads > 1:  # cmcts.cpp:98-107
@@ -83,7 +92,7 @@ class TreeBatch:
         if getattr(self.evaluator, "fused_layers", None) is not None:
             # the library's own network kernel: one call queues every step of the search
             try:
-                eng.simulate_net(n, self.evaluator.params.data_ptr(), self.evaluator.fused_layers, stream)
+                eng.simulate_net(n, self.evaluator.params.data_ptr(), self.evaluator.fused_layers, stream, sync=False)
             except _E.EngineError as e:
                 raise RuntimeError(str(e)) from None
             return
@@ -97,10 +106,6 @@ class TreeBatch:
                     else:
                         value, prior = self.evaluator(self.boards)
                     eng.expand_backup(value.data_ptr(), prior.data_ptr(), self.evaluator.log_priors, stream)
-        try:
-            eng.sync_check(stream)
-        except _E.EngineError as e:
-            raise RuntimeError(str(e)) from None
 
     def probs(self, trees=None):
         """Cmcts::get_prob (cmcts.cpp:317-341) for many trees: float32 [n, SIZE];
@@ -143,6 +148,34 @@ def choice_from_uniform(pi, u):
     cdf = np.cumsum(np.asarray(pi, np.float64))
     cdf /= cdf[-1]
     return int(min(np.searchsorted(cdf, u, side="right"), len(cdf) - 1))
+
+
+_M64 = (1 << 64) - 1
+
+
+def _mix64(x):
+    """splitmix64 finaliser on uint64 arrays (wrap-around arithmetic)."""
+    x = np.asarray(x, np.uint64)
+    with np.errstate(over="ignore"):
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)
+        return x ^ (x >> np.uint64(31))
+
+
+class KeyedUniform:
+    """The uniform number behind a sampled move as a function of (seed, game, half-move):
+    the host mirror of az_slots_choose's generator (include/azmcts.h), so a game's moves
+    depend on neither the tree slot nor the batch it is played in.  self_play_stream takes
+    one as its `rng`; self_play_resident computes the same numbers on the GPU."""
+
+    def __init__(self, seed):
+        self.seed = np.uint64(int(seed) & _M64)
+
+    def for_games(self, games, plies):
+        key = (np.asarray(games, np.uint64) << np.uint64(32)) | np.asarray(plies, np.uint64)
+        with np.errstate(over="ignore"):
+            x = _mix64(_mix64(self.seed ^ key) + np.uint64(0x9e3779b97f4a7c15))
+        return ((x >> np.uint64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
 
 
 def _choose_moves(pi, greedy, rng):
@@ -212,12 +245,32 @@ def self_play_games(batch0, batch1, sims, tau, init_moves=(), rng=None):
 
 class GameRecords(list):
     """Per-game record arrays (what the batched self-play drivers return) that are
-    consecutive slices of one array: `flat` is that array, so that writing or gathering
-    all records needs no concatenation."""
+    slices of one array, or of a few arrays (`pieces`, each holding whole games):
+    `flat` is all records as one array, so that writing or gathering them needs no
+    per-game concatenation."""
 
     def __init__(self, flat, bounds):
         super().__init__(flat[bounds[g]:bounds[g + 1]] for g in range(len(bounds) - 1))
-        self.flat = flat
+        self._flat = flat
+        self.pieces = [flat]
+
+    @classmethod
+    def from_pieces(cls, pieces, game_off, game_len):
+        """pieces: record arrays that follow one another in one record numbering;
+        game g = records [game_off[g], game_off[g] + game_len[g]), never split over two pieces."""
+        self = cls.__new__(cls)
+        starts = np.cumsum([0] + [len(p) for p in pieces])
+        which = np.searchsorted(starts, game_off, side="right") - 1
+        list.__init__(self, (pieces[w][o - starts[w]:o - starts[w] + n] for w, o, n in zip(which, game_off, game_len)))
+        self._flat = pieces[0] if len(pieces) == 1 else None
+        self.pieces = list(pieces)
+        return self
+
+    @property
+    def flat(self):
+        if self._flat is None:
+            self._flat = np.concatenate(self.pieces)
+        return self._flat
 
 
 def all_records(games):
@@ -415,7 +468,10 @@ def self_play_stream(batch0, batch1, sims, tau, n_games, init_moves=(), rng=None
         searcher.simulate(sims, alive)  # leaves exactly the live trees active
         u = np.full(G, -1.0)            # negative = greedy for that tree
         sampling = alive & (pair <= tau)
-        u[sampling] = rng.random(int(sampling.sum()))
+        if hasattr(rng, "for_games"):  # keyed by (game, half-move of the game) instead of drawn in slot order
+            u[sampling] = rng.for_games(game_of[sampling], 2 * pair[sampling] + side)
+        else:
+            u[sampling] = rng.random(int(sampling.sum()))
         d_u.copy_(torch.from_numpy(u))
         pi = torch.empty((G, size), dtype=torch.float32, device=dev)
         board = torch.empty((G, 2, S, S), dtype=torch.float32, device=dev)
@@ -452,6 +508,202 @@ def self_play_stream(batch0, batch1, sims, tau, n_games, init_moves=(), rng=None
     rec["r"] = np.where(decided, np.where(won == key[:, 1], 1.0, -1.0), 1e-3).astype(np.float32)
     bounds = np.searchsorted(key[:, 0], np.arange(n_games + 1))
     return GameRecords(rec, bounds)
+
+
+class _SlotLoop:
+    """Device arrays and the lagging host poll shared by the resident drivers."""
+
+    NEXT_GAME, FINISHED, RECORDS, ERRORS, ARENA_FULL, HALF_MOVES = range(6)  # AZ_SLOT_* of include/azmcts.h
+
+    def __init__(self, a, b, n_games, lag):
+        torch = a.torch
+        self.torch, self.a, self.b, self.n_games, self.lag = torch, a, b, n_games, max(1, int(lag))
+        self.dev = a.dev
+        G = a.n_trees
+        self.game_of = torch.full((G,), -1, dtype=torch.int32, device=self.dev)
+        self.ply = torch.zeros(G, dtype=torch.int32, device=self.dev)
+        self.counters = torch.zeros(8, dtype=torch.int32, device=self.dev)
+        self.outcome = torch.full((max(n_games, 1),), -1.0, dtype=torch.float32, device=self.dev)
+        self.ring = self.lag + 2
+        self.host = torch.zeros((self.ring, 8), dtype=torch.int32, pin_memory=True)
+        self.events = [None] * self.ring
+        self.half = 0
+
+    def mark(self):
+        """Behind the last call of a half-move: its counters start their way to the host."""
+        k = self.half % self.ring
+        self.host[k].copy_(self.counters, non_blocking=True)
+        ev = self.torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+        self.half += 1
+
+    def poll(self):
+        """Counters of the half-move `lag` behind the one just queued (None while fewer have been
+        queued): the host stays that far ahead of the GPU and never drains it."""
+        i = self.half - 1 - self.lag
+        if i < 0:
+            return None
+        return self._read(i)
+
+    def _read(self, i):
+        k = i % self.ring
+        self.events[k].synchronize()
+        c = self.host[k].numpy().copy()
+        if c[self.ERRORS]:
+            stream = self.torch.cuda.current_stream(self.dev).cuda_stream
+            for batch in (self.a, self.b):
+                try:
+                    batch.eng.sync_check(stream)
+                except _E.EngineError as e:
+                    raise RuntimeError(str(e)) from None
+            raise RuntimeError(f"{int(c[self.ERRORS])} trees in error")
+        if c[self.ARENA_FULL]:
+            raise RuntimeError("record arena full: give self_play_resident a larger arena_records")
+        return c
+
+    def last(self):
+        return self._read(self.half - 1)
+
+
+def self_play_resident(batch0, batch1, sims, tau, n_games, init_moves=(), seed=0, lag=3, arena_records=None):
+    """`n_games` games of `self_play_game` (src/self_play.py:134-202) on the G tree slots of the
+    two batches with NO host decision between two moves: which slot is idle, which game it gets,
+    sampling or greedy, the uniform number of a sampled move (KeyedUniform(seed), computed on the
+    GPU), the end of a game, the labels of its records and their place in the output all live in
+    device arrays (az_slots_* of the C ABI).  A half-move is a fixed sequence of launches; the
+    host queues them `lag` half-moves ahead of the GPU, reads the counters of the half-move that
+    far back, and copies the finished games' records (whole games, labelled, mcts0's records
+    first) from the device arena while the search goes on.
+    Same games as self_play_stream(..., rng=KeyedUniform(seed)), record for record.
+    Returns GameRecords in game order; `.pieces` are the record arrays in the order games finished."""
+    torch = batch0.torch
+    G, S, size = batch0.n_trees, batch0.shape, batch0.size
+    assert batch1.n_trees == G and batch1.shape == S
+    dev = batch0.dev
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    dt = sample_dtype(S)
+    rec = 3 * size + 1
+    assert dt.itemsize == rec * 4
+    if n_games <= 0:
+        return GameRecords(np.zeros(0, dt), np.zeros(1, np.int64))
+    max_plies = size  # a game ends with the board full at the latest
+    loop = _SlotLoop(batch0, batch1, n_games, lag)
+    e0, e1 = batch0.eng, batch1.eng
+    game_off = torch.zeros(n_games, dtype=torch.int32, device=dev)
+    game_len = torch.zeros(n_games, dtype=torch.int32, device=dev)
+    stage = torch.empty((G, max_plies, rec), dtype=torch.float32, device=dev)
+    if arena_records is None:
+        free = torch.cuda.mem_get_info(dev)[0]
+        arena_records = max(1, min(n_games * max_plies, int(free * 0.5) // (rec * 4), (1 << 31) - 1))
+    arena = torch.empty((arena_records, rec), dtype=torch.float32, device=dev)
+    d_act = torch.empty(G, dtype=torch.int32, device=dev)
+    openings = [int(m) for m in init_moves]
+    copier = torch.cuda.Stream(dev)
+    pieces, drained = [], 0
+
+    def drain(upto):  # records [drained, upto) are complete on the device: whole games
+        nonlocal drained
+        if upto > drained:
+            with torch.cuda.stream(copier):
+                pieces.append(arena[drained:upto].to("cpu").numpy().view(dt).reshape(-1))
+            drained = int(upto)
+
+    while True:
+        side = loop.half & 1
+        searcher = batch0 if side == 0 else batch1
+        try:
+            if side == 0:  # slots stay in phase: mcts0 of every live game searches the even half-moves
+                e0.slots_admit(e1, loop.game_of.data_ptr(), loop.ply.data_ptr(), loop.counters.data_ptr(), n_games, openings,
+                               stream)
+                if loop.half == 0:  # slots that got no game must not be searched (a new engine's trees are all active)
+                    e0.slots_turn(loop.game_of.data_ptr(), loop.ply.data_ptr(), False, -1, stream)
+                    e1.slots_turn(loop.game_of.data_ptr(), loop.ply.data_ptr(), False, -1, stream)
+            searcher.queue_simulate(sims)
+            searcher.eng.slots_choose(loop.game_of.data_ptr(), loop.ply.data_ptr(), tau, seed, d_act.data_ptr(),
+                                      stage.data_ptr(), max_plies, stream)
+            e0.make_move_device(d_act.data_ptr(), stream)
+            e1.make_move_device(d_act.data_ptr(), stream)
+            e0.slots_finish(e1, loop.game_of.data_ptr(), loop.ply.data_ptr(), loop.counters.data_ptr(),
+                            loop.outcome.data_ptr(), stage.data_ptr(), max_plies, arena.data_ptr(), arena_records,
+                            game_off.data_ptr(), game_len.data_ptr(), stream)
+        except _E.EngineError as e:
+            raise RuntimeError(str(e)) from None
+        loop.mark()
+        c = loop.poll()
+        if c is not None:
+            drain(c[loop.RECORDS])
+            if c[loop.FINISHED] >= n_games:
+                break
+    c = loop.last()  # the half-moves queued past the end found every slot idle
+    drain(c[loop.RECORDS])
+    try:
+        e0.sync_check(stream)
+        e1.sync_check(stream)
+    except _E.EngineError as e:
+        raise RuntimeError(str(e)) from None
+    out = GameRecords.from_pieces(pieces, game_off.cpu().numpy().astype(np.int64), game_len.cpu().numpy().astype(np.int64))
+    out.outcome = loop.outcome.cpu().numpy()[:n_games]
+    out.half_moves = loop.half
+    return out
+
+
+def eval_games_resident(best, latest, sims_best, sims_latest, n_games=None, init_moves=(), lag=3):
+    """The arena (src/eval.py:111-149 around eval_game :187-209) without a host decision between
+    two moves: game g is opened by `best` when g is even, each network searches the slots where it
+    is to move, always the first maximum; finished games free their slot for the next game
+    (n_games may exceed the number of slots; default: one game per slot).  Same tallies as
+    eval_games.  Returns (wins_best, wins_latest, draws)."""
+    torch = best.torch
+    G = best.n_trees
+    assert latest.n_trees == G and latest.shape == best.shape
+    n_games = G if n_games is None else int(n_games)
+    if n_games <= 0:
+        return 0, 0, 0
+    dev = best.dev
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    loop = _SlotLoop(best, latest, n_games, lag)
+    eb, el = best.eng, latest.eng
+    act_b = torch.empty(G, dtype=torch.int32, device=dev)
+    act_l = torch.empty(G, dtype=torch.int32, device=dev)
+    openings = [int(m) for m in init_moves]
+    gp, pp, cp = loop.game_of.data_ptr(), loop.ply.data_ptr(), loop.counters.data_ptr()
+    while True:
+        try:
+            eb.slots_admit(el, gp, pp, cp, n_games, openings, stream)
+            # `best` moves when game + half-move is even (it opens the even games, src/eval.py:117,134)
+            eb.slots_turn(gp, pp, True, 0, stream)
+            el.slots_turn(gp, pp, True, 1, stream)
+            best.queue_simulate(sims_best)
+            latest.queue_simulate(sims_latest)
+            eb.slots_choose(gp, pp, -1, 0, act_b.data_ptr(), None, 0, stream)  # always greedy (src/eval.py:192,202)
+            el.slots_choose(gp, pp, -1, 0, act_l.data_ptr(), None, 0, stream)
+            act = torch.maximum(act_b, act_l)  # every live game was searched by exactly one side
+            eb.make_move_device(act.data_ptr(), stream)
+            el.make_move_device(act.data_ptr(), stream)
+            eb.slots_finish(el, gp, pp, cp, loop.outcome.data_ptr(), stream=stream)
+        except _E.EngineError as e:
+            raise RuntimeError(str(e)) from None
+        loop.mark()
+        c = loop.poll()
+        if c is not None and c[loop.FINISHED] >= n_games:
+            break
+    loop.last()
+    try:
+        eb.sync_check(stream)
+        el.sync_check(stream)
+    except _E.EngineError as e:
+        raise RuntimeError(str(e)) from None
+    winner = loop.outcome.cpu().numpy()[:n_games]
+    first_player = len(openings) % 2  # the player to move once the opening has been played (src/eval.py:105)
+    second_player = 1 - first_player
+    best_opens = (np.arange(n_games) % 2) == 0
+    opener_won = winner == first_player
+    other_won = winner == second_player
+    draws = int((~(opener_won | other_won)).sum())
+    wins_best = int((opener_won & best_opens).sum() + (other_won & ~best_opens).sum())
+    wins_latest = int((opener_won & ~best_opens).sum() + (other_won & best_opens).sum())
+    return wins_best, wins_latest, draws
 
 
 def eval_games(best, latest, sims_best, sims_latest, init_moves=()):

@@ -132,7 +132,8 @@ int az_net_eval_masked(int shape, int n, const float *d_boards, const int *d_lea
 // launchers of az_slots.hip (device-resident bookkeeping of the callers' game loops; board-shape independent)
 int az_slots_launch_admit(AzTree *ta, AzTree *tb, int n, int *game_of, int *ply, int *counters, int n_games, unsigned char *mask,
                           hipStream_t st);
-int az_slots_launch_fill_actions(const unsigned char *mask, int n, int action, int *actions, hipStream_t st);
+int az_slots_launch_fill_actions(const unsigned char *mask, int n, int action, const int *per_game, const int *game_of, int *actions,
+                                 hipStream_t st);
 int az_slots_launch_turn(AzTree *trees, int n, const int *game_of, const int *ply, int by_game, int parity, hipStream_t st);
 int az_slots_launch_uniform(const int *game_of, const int *ply, int n, int tau, unsigned long long seed, double *u, hipStream_t st);
 int az_slots_launch_finish(AzTree *ta, AzTree *tb, int n, int *game_of, int *ply, int *counters, float *outcome, int with_records,

@@ -1012,10 +1012,11 @@ static int check_pair(const az_engine *a, const az_engine *b)
 }
 
 int az_slots_admit(az_engine *a, az_engine *b, int *d_game_of, int *d_ply, int *d_counters, int n_games, const int *openings,
-                   int n_open, void *stream)
+                   int n_open, const int *d_game_openings, int n_game_open, void *stream)
 {
     if (int rc = check_pair(a, b)) return rc;
-    if (!d_game_of || !d_ply || !d_counters || n_games < 0 || n_open < 0 || (n_open > 0 && !openings))
+    if (!d_game_of || !d_ply || !d_counters || n_games < 0 || n_open < 0 || (n_open > 0 && !openings) || n_game_open < 0 ||
+        (n_game_open > 0 && !d_game_openings))
         return fail(AZ_ERR_ARG, "bad argument");
     DeviceGuard g(a->device);
     hipStream_t st = (hipStream_t)stream;
@@ -1023,9 +1024,12 @@ int az_slots_admit(az_engine *a, az_engine *b, int *d_game_of, int *d_ply, int *
         return fail(AZ_ERR_HIP, "admit launch failed");
     if (a->ops->clear(a->P, a->d_mask, stream)) return fail(AZ_ERR_HIP, "clear launch failed");
     if (b && b->ops->clear(b->P, a->d_mask, stream)) return fail(AZ_ERR_HIP, "clear launch failed");
-    for (int k = 0; k < n_open; k++) { // the same opening for every game (tools.make_init_moves)
-        if (openings[k] < 0 || openings[k] >= a->size) return fail(AZ_ERR_INVALID_MOVE, "Invalid move %d (opening)", openings[k]);
-        if (az_slots_launch_fill_actions(a->d_mask, a->n_trees, openings[k], a->d_actions, st))
+    for (int k = 0; k < n_open + n_game_open; k++) {
+        // first the opening every game shares (tools.make_init_moves), then the game's own
+        const int *per_game = k < n_open ? nullptr : d_game_openings + (size_t)(k - n_open) * n_games;
+        const int action = k < n_open ? openings[k] : -1;
+        if (k < n_open && (action < 0 || action >= a->size)) return fail(AZ_ERR_INVALID_MOVE, "Invalid move %d (opening)", action);
+        if (az_slots_launch_fill_actions(a->d_mask, a->n_trees, action, per_game, d_game_of, a->d_actions, st))
             return fail(AZ_ERR_HIP, "opening launch failed");
         if (a->ops->make_move(a->P, a->d_actions, stream)) return fail(AZ_ERR_HIP, "make_move launch failed");
         if (b && b->ops->make_move(b->P, a->d_actions, stream)) return fail(AZ_ERR_HIP, "make_move launch failed");

@@ -82,11 +82,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_slots_admit(AzTree *ta, AzTree
     if (threadIdx.x == 0) counters[AZ_SLOT_NEXT_GAME] = next + min(total, room > 0 ? room : 0);
 }
 
-// actions[t] = action for the slots in `mask`, -1 (leave the tree alone) elsewhere
-__global__ void k_slots_fill_actions(const unsigned char *mask, int n, int action, int *actions)
+// actions[t] = the opening move for the slots in `mask`, -1 (leave the tree alone) elsewhere; the move is `action`
+// for every game, or per_game[game_of[t]] when per_game is given
+__global__ void k_slots_fill_actions(const unsigned char *mask, int n, int action, const int *per_game, const int *game_of, int *actions)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) actions[t] = mask[t] ? action : -1;
+    if (t < n) actions[t] = mask[t] ? (per_game != nullptr ? per_game[game_of[t]] : action) : -1;
 }
 
 // Which trees of an engine search this half-move: the live slots whose game has (ply + game * by_game) of the
@@ -134,15 +135,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_slots_finish(AzTree *ta, AzTre
     __syncthreads();
     const int per = (n + SCAN_THREADS - 1) / SCAN_THREADS;
     const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
-    int recs = 0, done = 0, bad = 0;
+    int recs = 0, done = 0, bad = 0, live = 0;
     for (int t = lo; t < hi; t++) {
         if (ta[t].err != 0 || (tb && tb[t].err != 0)) bad++;
+        if (game_of[t] >= 0) live++;
         if (game_of[t] >= 0 && ta[t].winner != -1.f) { recs += ply[t] + 1; done++; }
     }
     if (bad) atomicAdd(&s_err, bad);
     int total_recs, total_done;
     int at = block_exclusive_scan(recs, s_wave, total_recs);
     (void)block_exclusive_scan(done, s_wave, total_done);
+    int total_live;
+    (void)block_exclusive_scan(live, s_wave, total_live);
     const int cursor = counters[AZ_SLOT_RECORDS];
     const bool fits = !with_records || (long long)cursor + total_recs <= arena_records;
     for (int t = lo; t < hi; t++) {
@@ -177,6 +181,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_slots_finish(AzTree *ta, AzTre
         if (with_records && !fits) counters[AZ_SLOT_ARENA_FULL] = 1;
         counters[AZ_SLOT_ERRORS] = s_err; // trees in error right now (a tree in error never finishes its game)
         counters[AZ_SLOT_HALF_MOVES] += 1;
+        counters[AZ_SLOT_TREE_MOVES] += total_live;
     }
 }
 
@@ -214,9 +219,10 @@ int az_slots_launch_admit(AzTree *ta, AzTree *tb, int n, int *game_of, int *ply,
     hipLaunchKernelGGL(k_slots_admit, dim3(1), dim3(SCAN_THREADS), 0, st, ta, tb, n, game_of, ply, counters, n_games, mask);
     return status();
 }
-int az_slots_launch_fill_actions(const unsigned char *mask, int n, int action, int *actions, hipStream_t st)
+int az_slots_launch_fill_actions(const unsigned char *mask, int n, int action, const int *per_game, const int *game_of, int *actions,
+                                 hipStream_t st)
 {
-    hipLaunchKernelGGL(k_slots_fill_actions, dim3((n + 255) / 256), dim3(256), 0, st, mask, n, action, actions);
+    hipLaunchKernelGGL(k_slots_fill_actions, dim3((n + 255) / 256), dim3(256), 0, st, mask, n, action, per_game, game_of, actions);
     return status();
 }
 int az_slots_launch_turn(AzTree *trees, int n, const int *game_of, const int *ply, int by_game, int parity, hipStream_t st)

@@ -83,7 +83,7 @@ SYMBOLS = [
     ("az_sync_states", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("az_make_move_greedy", _i, [_vp, _vp]),
     ("az_restart_finished", _i, [_vp, _vp, _i, _vp, _vp]),
-    ("az_slots_admit", _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    ("az_slots_admit", _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp]),
     ("az_slots_turn", _i, [_vp, _vp, _vp, _i, _i, _vp]),
     ("az_slots_choose", _i, [_vp, _vp, _vp, _i, _ull, _vp, _vp, _i, _vp]),
     ("az_slots_finish", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, C.c_longlong, _vp, _vp, _vp]),
@@ -363,10 +363,12 @@ class Engine:
                                                _ptr(d_count) if d_count is not None else None, stream))
 
     # ---- device-resident game loops (slot bookkeeping in device arrays; everything asynchronous)
-    def slots_admit(self, other, d_game_of, d_ply, d_counters, n_games, openings=(), stream=None):
+    def slots_admit(self, other, d_game_of, d_ply, d_counters, n_games, openings=(), stream=None, d_game_openings=None,
+                    n_game_open=0):
         op = np.ascontiguousarray(openings, np.int32)
         self._check(self.L.az_slots_admit(self.h, other.h if other is not None else None, _ptr(d_game_of), _ptr(d_ply),
-                                          _ptr(d_counters), int(n_games), _ptr(op) if op.size else None, int(op.size), stream))
+                                          _ptr(d_counters), int(n_games), _ptr(op) if op.size else None, int(op.size),
+                                          _ptr(d_game_openings) if n_game_open else None, int(n_game_open), stream))
 
     def slots_turn(self, d_game_of, d_ply, by_game, parity, stream=None):
         self._check(self.L.az_slots_turn(self.h, _ptr(d_game_of), _ptr(d_ply), int(bool(by_game)), int(parity), stream))

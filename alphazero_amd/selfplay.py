@@ -9,6 +9,8 @@ they shard over GPUs with no collective inside the search (gather_samples /
 reduce_counters are the only exchanges, over RCCL when launched with one
 process per GPU).
 """
+import time
+
 import numpy as np
 
 from . import engine as _E
@@ -513,9 +515,9 @@ def self_play_stream(batch0, batch1, sims, tau, n_games, init_moves=(), rng=None
 class _SlotLoop:
     """Device arrays and the lagging host poll shared by the resident drivers."""
 
-    NEXT_GAME, FINISHED, RECORDS, ERRORS, ARENA_FULL, HALF_MOVES = range(6)  # AZ_SLOT_* of include/azmcts.h
+    NEXT_GAME, FINISHED, RECORDS, ERRORS, ARENA_FULL, HALF_MOVES, TREE_MOVES = range(7)  # AZ_SLOT_* of include/azmcts.h
 
-    def __init__(self, a, b, n_games, lag):
+    def __init__(self, a, b, n_games, lag, init_moves=(), game_openings=None):
         torch = a.torch
         self.torch, self.a, self.b, self.n_games, self.lag = torch, a, b, n_games, max(1, int(lag))
         self.dev = a.dev
@@ -528,6 +530,17 @@ class _SlotLoop:
         self.host = torch.zeros((self.ring, 8), dtype=torch.int32, pin_memory=True)
         self.events = [None] * self.ring
         self.half = 0
+        self.timeline = []  # (host time, half-move, games started, games finished, moves played) per poll
+        self.openings = [int(m) for m in init_moves]
+        self.d_game_openings, self.n_game_open = None, 0
+        if game_openings is not None:
+            op = np.ascontiguousarray(game_openings, np.int32).reshape(-1, n_games)
+            self.d_game_openings, self.n_game_open = torch.from_numpy(op).to(self.dev), op.shape[0]
+
+    def admit(self, stream):
+        self.a.eng.slots_admit(self.b.eng, self.game_of.data_ptr(), self.ply.data_ptr(), self.counters.data_ptr(), self.n_games,
+                               self.openings, stream,
+                               self.d_game_openings.data_ptr() if self.n_game_open else None, self.n_game_open)
 
     def mark(self):
         """Behind the last call of a half-move: its counters start their way to the host."""
@@ -560,13 +573,23 @@ class _SlotLoop:
             raise RuntimeError(f"{int(c[self.ERRORS])} trees in error")
         if c[self.ARENA_FULL]:
             raise RuntimeError("record arena full: give self_play_resident a larger arena_records")
+        self.timeline.append((time.perf_counter(), i, int(c[self.NEXT_GAME]), int(c[self.FINISHED]), int(c[self.TREE_MOVES])))
         return c
+
+    def steady_moves_per_s(self):
+        """Moves per second (summed over the slots) between the first poll and the last poll at which games were
+        still waiting for a slot, i.e. while every slot was busy; None when that window is empty."""
+        busy = [p for p in self.timeline if p[2] < self.n_games]
+        if len(busy) < 2 or busy[-1][0] <= busy[0][0]:
+            return None
+        return (busy[-1][4] - busy[0][4]) / (busy[-1][0] - busy[0][0])
 
     def last(self):
         return self._read(self.half - 1)
 
 
-def self_play_resident(batch0, batch1, sims, tau, n_games, init_moves=(), seed=0, lag=3, arena_records=None):
+def self_play_resident(batch0, batch1, sims, tau, n_games, init_moves=(), seed=0, lag=3, arena_records=None,
+                       game_openings=None):
     """`n_games` games of `self_play_game` (src/self_play.py:134-202) on the G tree slots of the
     two batches with NO host decision between two moves: which slot is idle, which game it gets,
     sampling or greedy, the uniform number of a sampled move (KeyedUniform(seed), computed on the
@@ -576,7 +599,10 @@ def self_play_resident(batch0, batch1, sims, tau, n_games, init_moves=(), seed=0
     far back, and copies the finished games' records (whole games, labelled, mcts0's records
     first) from the device arena while the search goes on.
     Same games as self_play_stream(..., rng=KeyedUniform(seed)), record for record.
-    Returns GameRecords in game order; `.pieces` are the record arrays in the order games finished."""
+    game_openings (int [k][n_games] or [n_games], optional): moves of its own that game g plays after
+    init_moves, before the first search.
+    Returns GameRecords in game order; `.pieces` are the record arrays in the order games finished,
+    `.loop` the bookkeeping object (poll timeline, steady_moves_per_s)."""
     torch = batch0.torch
     G, S, size = batch0.n_trees, batch0.shape, batch0.size
     assert batch1.n_trees == G and batch1.shape == S
@@ -588,7 +614,7 @@ def self_play_resident(batch0, batch1, sims, tau, n_games, init_moves=(), seed=0
     if n_games <= 0:
         return GameRecords(np.zeros(0, dt), np.zeros(1, np.int64))
     max_plies = size  # a game ends with the board full at the latest
-    loop = _SlotLoop(batch0, batch1, n_games, lag)
+    loop = _SlotLoop(batch0, batch1, n_games, lag, init_moves, game_openings)
     e0, e1 = batch0.eng, batch1.eng
     game_off = torch.zeros(n_games, dtype=torch.int32, device=dev)
     game_len = torch.zeros(n_games, dtype=torch.int32, device=dev)
@@ -598,7 +624,6 @@ def self_play_resident(batch0, batch1, sims, tau, n_games, init_moves=(), seed=0
         arena_records = max(1, min(n_games * max_plies, int(free * 0.5) // (rec * 4), (1 << 31) - 1))
     arena = torch.empty((arena_records, rec), dtype=torch.float32, device=dev)
     d_act = torch.empty(G, dtype=torch.int32, device=dev)
-    openings = [int(m) for m in init_moves]
     copier = torch.cuda.Stream(dev)
     pieces, drained = [], 0
 
@@ -614,8 +639,7 @@ def self_play_resident(batch0, batch1, sims, tau, n_games, init_moves=(), seed=0
         searcher = batch0 if side == 0 else batch1
         try:
             if side == 0:  # slots stay in phase: mcts0 of every live game searches the even half-moves
-                e0.slots_admit(e1, loop.game_of.data_ptr(), loop.ply.data_ptr(), loop.counters.data_ptr(), n_games, openings,
-                               stream)
+                loop.admit(stream)
                 if loop.half == 0:  # slots that got no game must not be searched (a new engine's trees are all active)
                     e0.slots_turn(loop.game_of.data_ptr(), loop.ply.data_ptr(), False, -1, stream)
                     e1.slots_turn(loop.game_of.data_ptr(), loop.ply.data_ptr(), False, -1, stream)
@@ -645,15 +669,18 @@ def self_play_resident(batch0, batch1, sims, tau, n_games, init_moves=(), seed=0
     out = GameRecords.from_pieces(pieces, game_off.cpu().numpy().astype(np.int64), game_len.cpu().numpy().astype(np.int64))
     out.outcome = loop.outcome.cpu().numpy()[:n_games]
     out.half_moves = loop.half
+    out.loop = loop
     return out
 
 
-def eval_games_resident(best, latest, sims_best, sims_latest, n_games=None, init_moves=(), lag=3):
+def eval_games_resident(best, latest, sims_best, sims_latest, n_games=None, init_moves=(), lag=3, game_openings=None,
+                        info=None):
     """The arena (src/eval.py:111-149 around eval_game :187-209) without a host decision between
     two moves: game g is opened by `best` when g is even, each network searches the slots where it
     is to move, always the first maximum; finished games free their slot for the next game
     (n_games may exceed the number of slots; default: one game per slot).  Same tallies as
-    eval_games.  Returns (wins_best, wins_latest, draws)."""
+    eval_games.  game_openings: as in self_play_resident.  info (dict, optional) receives the bookkeeping object
+    under "loop".  Returns (wins_best, wins_latest, draws)."""
     torch = best.torch
     G = best.n_trees
     assert latest.n_trees == G and latest.shape == best.shape
@@ -662,15 +689,16 @@ def eval_games_resident(best, latest, sims_best, sims_latest, n_games=None, init
         return 0, 0, 0
     dev = best.dev
     stream = torch.cuda.current_stream(dev).cuda_stream
-    loop = _SlotLoop(best, latest, n_games, lag)
+    loop = _SlotLoop(best, latest, n_games, lag, init_moves, game_openings)
+    if info is not None:
+        info["loop"] = loop
     eb, el = best.eng, latest.eng
     act_b = torch.empty(G, dtype=torch.int32, device=dev)
     act_l = torch.empty(G, dtype=torch.int32, device=dev)
-    openings = [int(m) for m in init_moves]
     gp, pp, cp = loop.game_of.data_ptr(), loop.ply.data_ptr(), loop.counters.data_ptr()
     while True:
         try:
-            eb.slots_admit(el, gp, pp, cp, n_games, openings, stream)
+            loop.admit(stream)
             # `best` moves when game + half-move is even (it opens the even games, src/eval.py:117,134)
             eb.slots_turn(gp, pp, True, 0, stream)
             el.slots_turn(gp, pp, True, 1, stream)
@@ -695,7 +723,8 @@ def eval_games_resident(best, latest, sims_best, sims_latest, n_games=None, init
     except _E.EngineError as e:
         raise RuntimeError(str(e)) from None
     winner = loop.outcome.cpu().numpy()[:n_games]
-    first_player = len(openings) % 2  # the player to move once the opening has been played (src/eval.py:105)
+    # the player to move once the opening has been played (src/eval.py:105)
+    first_player = (len(loop.openings) + loop.n_game_open) % 2
     second_player = 1 - first_player
     best_opens = (np.arange(n_games) % 2) == 0
     opener_won = winner == first_player

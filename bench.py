@@ -383,7 +383,7 @@ def secondary_net(torch, E, dev_index, trees=8192, shape=SHAPE, sims=SIMS, label
         return {"workload": label, "error": f"{type(e).__name__}: {e}"}
 
 
-def secondary_games(torch, dev_index, mode, games=4096, shape=SHAPE, sims=100, tau=10, slots=0):
+def secondary_games(torch, dev_index, mode, games=4096, shape=SHAPE, sims=100, tau=10, slots=0, resident=False):
     """Whole games end to end on one GPU through the batched drivers: `self_play_game`
     (src/self_play.py:134-202; records assembled on the host, as the sample gather takes
     them) or the arena's `eval_game` with two networks and the noise on (src/eval.py:187-209,
@@ -404,7 +404,7 @@ def secondary_games(torch, dev_index, mode, games=4096, shape=SHAPE, sims=100, t
         b0 = sp.TreeBatch(width, shape, nets[0], cpuct=CPUCT, eps=0.25, nodes_per_tree=nodes, device=dev_index, noise_seed=0)
         b1 = sp.TreeBatch(width, shape, second, cpuct=CPUCT, eps=0.25, nodes_per_tree=nodes, device=dev_index, noise_seed=1000)
         try:
-            if slots == 0:
+            if slots == 0 and not resident:
                 first = np.arange(games, dtype=np.int32) % (shape * shape)  # distinct first stones
                 b0.make_move(first)
                 b1.make_move(first)
@@ -412,8 +412,20 @@ def secondary_games(torch, dev_index, mode, games=4096, shape=SHAPE, sims=100, t
             t0 = time.perf_counter()
             rec = {"workload": f"{mode}: {games} games of {shape}x{shape} to the end, {sims} sims/move, reference net "
                                f"(seed 0{'' if mode == 'selfplay' else ' vs seed 1'}), eps=0.25, cpuct=4"
-                               + (f", {slots} tree slots per batch, a finished game's slot goes to the next game" if slots else "")}
-            if mode == "selfplay" and slots > 0:
+                               + (f", {slots} tree slots per batch, a finished game's slot goes to the next game" if slots else "")
+                               + (", game loop resident on the GPU (az_slots_*)" if resident else "")}
+            loop = None
+            if mode == "selfplay" and slots > 0 and resident:
+                data = sp.self_play_resident(b0, b1, sims, tau, games, seed=0)
+                n_samples = sum(len(p) for p in data.pieces)
+                loop = data.loop
+            elif mode == "arena" and resident:
+                info = {}
+                first = np.arange(games, dtype=np.int32) % (shape * shape)  # distinct first stones, as in the host-stepped leg
+                rec["wins_first_net"], rec["wins_second_net"], rec["draws"] = (
+                    int(x) for x in sp.eval_games_resident(b0, b1, sims, sims, n_games=games, game_openings=first, info=info))
+                loop = info["loop"]
+            elif mode == "selfplay" and slots > 0:
                 data = sp.self_play_stream(b0, b1, sims, tau, games, rng=np.random.default_rng(0))
                 n_samples = sum(len(g) for g in data)
             elif mode == "selfplay":
@@ -426,6 +438,14 @@ def secondary_games(torch, dev_index, mode, games=4096, shape=SHAPE, sims=100, t
             wall = time.perf_counter() - t0
             total = b0.eng.get_stats()["sims"] + b1.eng.get_stats()["sims"]
             rec.update({"value": total / wall, "unit": "sims/s", "wall_s": wall, "games_per_s": games / wall})
+            if loop is not None:
+                rec["half_moves_queued"] = loop.half
+                steady = loop.steady_moves_per_s()
+                if steady is not None:  # while games were still waiting for a slot: every slot busy
+                    rec["steady_value"] = steady * sims
+                    rec["steady_note"] = ("sims/s between the first poll and the last poll with games still waiting for a "
+                                          "slot (every slot busy); `value` is the whole run, start-up, the thinning tail of "
+                                          "the last games and the read-back of the records included")
             if mode == "selfplay":
                 rec.update({"samples": n_samples, "samples_per_s": n_samples / wall})
             return rec
@@ -523,7 +543,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--only", default=None,
                     help="run one secondary workload alone and print its record (for profiling): "
-                         + ", ".join(list(HASH_WORKLOADS) + ["config3", "config4_share", "config3_games", "config3_stream", "config5_share", "config1_one_tree"]))
+                         + ", ".join(list(HASH_WORKLOADS) + ["config3", "config4_share", "config3_games", "config3_stream", "config3_stream_host", "config5_share", "config5_share_host", "config1_one_tree"]))
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -567,8 +587,10 @@ def main():
         rec = (secondary_net(torch, E, dev_index) if args.only == "config3"
                else config4_share(torch, E, dev_index) if args.only == "config4_share"
                else secondary_games(torch, dev_index, "selfplay") if args.only == "config3_games"
-               else secondary_games(torch, dev_index, "selfplay", games=16384, slots=8192) if args.only == "config3_stream"
-               else secondary_games(torch, dev_index, "arena") if args.only == "config5_share"
+               else secondary_games(torch, dev_index, "selfplay", games=49152, slots=8192, resident=True) if args.only == "config3_stream"
+               else secondary_games(torch, dev_index, "selfplay", games=16384, slots=8192) if args.only == "config3_stream_host"
+               else secondary_games(torch, dev_index, "arena", games=32768, slots=16384, resident=True) if args.only == "config5_share"
+               else secondary_games(torch, dev_index, "arena") if args.only == "config5_share_host"
                else one_tree_latency(torch, dev_index) if args.only == "config1_one_tree"
                else secondary_hash(torch, E, dev_index, args.only, *HASH_WORKLOADS[args.only], traffic))
         print(json.dumps(rec), flush=True)
@@ -633,8 +655,12 @@ def main():
                 "config3": secondary_net(torch, E, dev_index),
                 "config4_share": config4_share(torch, E, dev_index),
                 "config3_games": secondary_games(torch, dev_index, "selfplay"),
-                "config3_stream": secondary_games(torch, dev_index, "selfplay", games=16384, slots=8192),
-                "config5_share": secondary_games(torch, dev_index, "arena"),
+                # whole games, the loop resident on the GPU (self_play_resident / eval_games_resident)
+                "config3_stream": secondary_games(torch, dev_index, "selfplay", games=49152, slots=8192, resident=True),
+                "config5_share": secondary_games(torch, dev_index, "arena", games=32768, slots=16384, resident=True),
+                # the host-stepped drivers (a host decision per half-move), for comparison
+                "config3_stream_host": secondary_games(torch, dev_index, "selfplay", games=16384, slots=8192),
+                "config5_share_host": secondary_games(torch, dev_index, "arena"),
                 "config1_one_tree": one_tree_latency(torch, dev_index),
             }
         print(json.dumps(out), flush=True)

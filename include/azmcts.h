@@ -292,14 +292,17 @@ enum {
     AZ_SLOT_ERRORS = 3,    /* trees in error at the last az_slots_finish (their games stall) */
     AZ_SLOT_ARENA_FULL = 4,/* set when a finished game's records did not fit the arena      */
     AZ_SLOT_HALF_MOVES = 5,/* az_slots_finish calls so far                                  */
+    AZ_SLOT_TREE_MOVES = 6,/* moves played so far, summed over the slots (live slots per half-move) */
     AZ_SLOT_COUNTERS = 8
 };
 /* Loop head (src/self_play.py:86-91, src/eval.py:111-116): every idle slot, in slot order,
  * takes the next game while fewer than n_games have been started: Cmcts::clear on its
- * tree(s), then the opening moves `openings[0..n_open)` (host array; tools.make_init_moves,
- * src/tools.py:41-44), ply = 0, trees active. */
+ * tree(s), then the opening moves `openings[0..n_open)` (host array, the same for every
+ * game: tools.make_init_moves with INIT_MOVES, src/tools.py:41-44), then the game's own
+ * opening moves d_game_openings[k][game], k < n_game_open (device int32 [n_game_open][n_games],
+ * may be NULL; a negative entry plays nothing), ply = 0, trees active. */
 int az_slots_admit(az_engine *a, az_engine *b, int *d_game_of, int *d_ply, int *d_counters, int n_games,
-                   const int *openings, int n_open, void *stream);
+                   const int *openings, int n_open, const int *d_game_openings, int n_game_open, void *stream);
 /* Which trees of `e` search next: the live slots whose (ply + game * by_game) has the given
  * parity (the arena's networks take turns opening, src/eval.py:117,134; mcts0 searches the
  * even half-moves, src/self_play.py:156,172); parity < 0: every live slot. */

@@ -114,3 +114,39 @@ def test_resident_arena_equals_host_arena(eps, init):
     assert sp.eval_games_resident(best, latest, sb, sl, n_games=n_games, init_moves=init, lag=2) == want
     best.close(); latest.close()
     assert sum(want) == n_games
+
+
+def test_resident_loops_with_an_opening_of_its_own_per_game():
+    """game_openings: game g starts from its own first stone (what a host loop does with make_move before
+    the first search): arena tallies and self-play records equal the host-stepped drivers'."""
+    from alphazero_amd import selfplay as sp
+
+    S, sims, n_games = 7, 24, 10
+    first = (np.arange(n_games) * 5 + 3) % (S * S)
+    best, latest = _pair(n_games, S, 40, 0.25, noise_seeds=(0, 1000))
+    for b in (best, latest):
+        b.make_move(first.astype(np.int32))
+    want = sp.eval_games_device(best, latest, sims, sims)
+    best.close(); latest.close()
+    best, latest = _pair(3, S, 40, 0.25, noise_seeds=(0, 1000))
+    info = {}
+    got = sp.eval_games_resident(best, latest, sims, sims, n_games=n_games, game_openings=first, info=info)
+    best.close(); latest.close()
+    assert got == want
+    tl = info["loop"].timeline
+    assert tl[-1][3] == n_games and tl[-1][4] > 0  # every game finished; moves were counted
+    # self-play: the same opening stone per game through the host-stepped stream driver is not expressible
+    # (its openings are shared), so compare game by game against one-game batches
+    b0, b1 = _pair(3, S, 40, 0.0)
+    got = sp.self_play_resident(b0, b1, sims, 1, n_games, seed=4, game_openings=first)
+    b0.close(); b1.close()
+    for g in (0, 4, 9):
+        b0, b1 = _pair(1, S, 40, 0.0)
+
+        class OneGame(sp.KeyedUniform):  # game 0 of the one-game batch draws game g's numbers
+            def for_games(self, games, plies):
+                return super().for_games(np.full_like(np.asarray(games), g), plies)
+
+        one = sp.self_play_stream(b0, b1, sims, 1, 1, init_moves=(int(first[g]),), rng=OneGame(4))
+        b0.close(); b1.close()
+        _same_games([got[g]], one)

@@ -1673,7 +1673,8 @@ __global__ __launch_bounds__(64) void k_choose_moves(AzParams P, const double *d
 // normals by Box-Muller.  Not GSL's stream: validated statistically.
 __device__ __forceinline__ double u01(unsigned long long seed, unsigned row, unsigned a, unsigned j)
 {
-    const unsigned long long x = mix64(mix64(seed ^ ((unsigned long long)row << 32 | a)) + 0x9e3779b97f4a7c15ull * ((unsigned long long)j + 1ull));
+    // (the seed is hashed first: seeds that differ in a few low bits must not give tables that are permutations of each other)
+    const unsigned long long x = mix64(mix64(mix64(seed) ^ ((unsigned long long)row << 32 | a)) + 0x9e3779b97f4a7c15ull * ((unsigned long long)j + 1ull));
     return ((double)(x >> 11) + 0.5) * (1.0 / 9007199254740992.0); // in (0, 1)
 }
 __device__ double gamma_draw(double alpha, unsigned long long seed, unsigned row, unsigned a)

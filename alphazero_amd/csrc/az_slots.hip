@@ -114,7 +114,8 @@ __global__ void k_slots_uniform(const int *game_of, const int *ply, int n, int t
     const int g = game_of[t], p = ply[t];
     double v = -1.;
     if (g >= 0 && (p >> 1) <= tau) {
-        const unsigned long long x = mix64(mix64(seed ^ ((unsigned long long)(unsigned)g << 32 | (unsigned)p)) + 0x9e3779b97f4a7c15ull);
+        // (the seed is hashed first, so that neighbouring seeds -- one per rank, say -- give unrelated streams)
+        const unsigned long long x = mix64(mix64(mix64(seed) ^ ((unsigned long long)(unsigned)g << 32 | (unsigned)p)) + 0x9e3779b97f4a7c15ull);
         v = ((double)(x >> 11) + 0.5) * (1.0 / 9007199254740992.0); // in (0, 1)
     }
     u[t] = v;

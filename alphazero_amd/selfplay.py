@@ -171,7 +171,7 @@ class KeyedUniform:
     one as its `rng`; self_play_resident computes the same numbers on the GPU."""
 
     def __init__(self, seed):
-        self.seed = np.uint64(int(seed) & _M64)
+        self.seed = _mix64(np.uint64(int(seed) & _M64))  # hashed: neighbouring seeds give unrelated streams
 
     def for_games(self, games, plies):
         key = (np.asarray(games, np.uint64) << np.uint64(32)) | np.asarray(plies, np.uint64)

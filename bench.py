@@ -250,22 +250,50 @@ def run_tree_workload(torch, E, dev_index, first_game, trees, shape, eval_kind, 
         eng.close()
 
 
-def tree_roofline(res, trees, shape, traffic=None):
+def padded_actions(shape):
+    """SP of the node records (az_kernels.hip): the board's cells padded to a multiple of 64 * ceil(cells / 256)."""
     size = shape * shape
-    depth = res["select_calls"] / max(1, res["sims"])
+    e4 = (size + 255) // 256
+    return (size + 64 * e4 - 1) // (64 * e4) * 64 * e4
+
+
+def design_bytes_per_sim(depth, expansions_per_sim, shape, sims_per_launch):
+    """What one search of the fused kernel moves between the CUs and the memory system, by design:
+    the root scan is served from registers (0 B); every select below the root touches one record of
+    24 B per padded action (a visited node is read whole; a fresh one has its 8 B priors read and its
+    16 B of N / LINK / W written by that first select) plus 12 B for the visit count and link; an
+    expansion writes 8 B of priors per padded action; the backup writes 8 B per level; the root record
+    is read and written back once per launch.  An upper bound on the HBM traffic: records re-read
+    within a short time come from the L2."""
+    sp = padded_actions(shape)
+    below = max(0.0, depth - 1.0)
+    return below * (24 * sp + 12) + expansions_per_sim * 8 * sp + below * 8 + 48.0 * sp / sims_per_launch
+
+
+def tree_roofline(res, trees, shape, traffic=None, traffic_source=None):
+    size = shape * shape
+    sims = max(1, res["sims"])
+    depth = res["select_calls"] / sims
     bps = algorithmic_bytes_per_sim(depth, size)
+    dps = design_bytes_per_sim(depth, res["expansions"] / sims, shape, SIMS)
     avg_s = float(np.mean(res["kernel_ms"])) / 1e3
     achieved = trees * SIMS * bps / avg_s / 1e9
+    design = trees * SIMS * dps / avg_s / 1e9
     out = {"bound": "hbm", "kernel": "k_simulate_fused", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_sim": bps, "sims_per_launch": trees * SIMS,
-           "avg_launch_ms": avg_s * 1e3, "mean_select_depth": depth}
+           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "bytes_per_sim": bps,
+           "sims_per_launch": trees * SIMS, "avg_launch_ms": avg_s * 1e3, "mean_select_depth": depth,
+           "design_bytes_per_sim": dps, "design_bytes_per_launch": trees * SIMS * dps, "design_gbs": design,
+           "design_frac": design / HBM_PEAK_GBS}
     if traffic:
         out["hbm_gbs"] = traffic / avg_s / 1e9
         out["hbm_frac"] = out["hbm_gbs"] / HBM_PEAK_GBS
+        out["traffic_over_design"] = traffic / (trees * SIMS * dps)
     if out["frac"] > 1.0:
-        out["note"] = ("frac prices every select as a dense scan of 20 B per child from memory; the root's statistics "
-                       "live in registers for the whole launch and fresh nodes hold priors only, so the algorithmic "
-                       "figure can pass the peak: hbm_frac (measured traffic) is the memory system's share")
+        out["note"] = ("frac prices every select as a dense scan of 20 B per child from memory (the algorithmic model); the "
+                       "root's statistics live in registers for the whole launch and fresh nodes hold priors only, so that "
+                       "figure can pass the peak: it is a measure of work done, not of bytes moved.  design_frac prices the "
+                       "bytes the kernel requests by design (root scans excluded), hbm_frac the bytes the TCC counters saw "
+                       "reach HBM in the profile named by traffic_source: both are at most 1")
     return out
 
 
@@ -281,7 +309,8 @@ def secondary_hash(torch, E, dev_index, name, trees, shape, nodes, traffic):
         res = run_tree_workload(torch, E, dev_index, 0, trees, shape, E.EVAL_HASH, nodes, warmup=3, min_seconds=0.6)
     except Exception as e:  # reported, never fatal for the headline line
         return {"workload": name, "error": f"{type(e).__name__}: {e}"}
-    roof = tree_roofline(res, trees, shape, traffic.get(name, {}).get("hbm_bytes_per_launch"))
+    roof = tree_roofline(res, trees, shape, traffic.get(name, {}).get("hbm_bytes_per_launch"),
+                         ("profiles/" + traffic[name]["source"]) if name in traffic and "source" in traffic[name] else None)
     return {
         "workload": name, "trees": trees, "shape": shape, "nodes_per_tree": nodes, "evaluator": "hash (in-kernel)",
         "value": res["sims"] / res["elapsed"], "unit": "sims/s", "steps": res["steps"],
@@ -503,6 +532,141 @@ HASH_WORKLOADS = {
 }
 
 
+# ------------------------------------------------------------------ N > 1: what the node proves about itself
+def rank_census(torch, dist, rank, world, dev_index, cdev, stub=False):
+    """Collective evidence that `world` ranks sit on `world` different GPUs: an all_reduce(SUM) of ones
+    over the bench's own backend (RCCL on a GPU node) and the all_gather of every rank's device identity
+    (index and PCI address).  Every rank calls it; every rank gets the same record."""
+    ones = torch.ones(1, dtype=torch.int64, device=cdev)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    ident = [rank, dev_index, -1, -1, -1, 0]
+    name = "stub (no GPU)"
+    if not stub:
+        props = torch.cuda.get_device_properties(dev_index)
+        name = props.name
+        ident[2:5] = [int(getattr(props, k, -1)) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+        ident[5] = int.from_bytes(str(getattr(props, "uuid", "")).encode()[-6:] or b"\0", "little") & 0x7FFFFFFFFFFF
+    mine = torch.tensor(ident, dtype=torch.int64, device=cdev)
+    everyone = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(everyone, mine)
+    rows = [[int(x) for x in t.cpu().tolist()] for t in everyone]
+    devices = [{"rank": r[0], "device_index": r[1], "pci": f"{r[2]:04x}:{r[3]:02x}:{r[4]:02x}" if r[3] >= 0 else None,
+                "uuid_tail": r[5]} for r in rows]
+    distinct = len({(d["pci"], d["uuid_tail"]) if d["pci"] else ("idx", d["device_index"], d["rank"] if stub else 0) for d in devices})
+    return {"rccl_ranks": int(ones.item()), "backend": dist.get_backend(), "device_name": name, "devices": devices,
+            "distinct_devices": distinct}
+
+
+def _all_ok(torch, dist, ok, cdev):
+    """True when every rank's leg went through: decided by a collective, so that no rank enters the
+    exchange that follows while another has given up."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=cdev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+
+
+def _max_over_ranks(torch, dist, values, cdev):
+    t = torch.tensor(values, dtype=torch.float64, device=cdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(x) for x in t.cpu().tolist()]
+
+
+def node_config4(torch, dist, rank, world, dev_index, cdev, games_per_rank, sims=100, shape=20, tau=10):
+    """Config 4 on the node: games_per_rank x world games of 20x20 (65,536 = 8,192 per GPU x 8), each rank
+    plays its contiguous shard to the end with the loop resident on its GPU (no collective in the search),
+    then the sample records of all ranks are gathered on rank 0 over the bench's backend (RCCL)."""
+    from alphazero_amd import selfplay as sp
+    from alphazero_amd.evaluator import FusedNetEvaluator
+    from alphazero_amd.model import PolicyValueNet
+
+    label = f"config4: {games_per_rank * world} games of {shape}x{shape} = {games_per_rank} per GPU x {world}"
+    local, err, t_play, sims_done = None, None, 0.0, 0
+    try:
+        dev = torch.device("cuda", dev_index)
+        lo, hi = sp.shard_range(games_per_rank * world, rank, world)
+        torch.manual_seed(rank)  # replicas start apart; the broadcast makes them rank 0's
+        ev = FusedNetEvaluator(PolicyValueNet(shape).eval(), shape, dev)
+        sp.broadcast_parameters(ev)
+        slots = min(8192, hi - lo)
+        nodes = sims * 3 + 64
+        b0 = sp.TreeBatch(slots, shape, ev, cpuct=CPUCT, eps=0.25, nodes_per_tree=nodes, device=dev_index, noise_seed=2 * rank)
+        b1 = sp.TreeBatch(slots, shape, ev, cpuct=CPUCT, eps=0.25, nodes_per_tree=nodes, device=dev_index, noise_seed=2 * rank + 1)
+        try:
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            t0 = time.perf_counter()
+            data = sp.self_play_resident(b0, b1, sims, tau, hi - lo, seed=1000 + rank)
+            torch.cuda.synchronize(dev)
+            t_play = time.perf_counter() - t0
+            local = data.flat
+            sims_done = b0.eng.get_stats()["sims"] + b1.eng.get_stats()["sims"]
+        finally:
+            b0.close()
+            b1.close()
+    except Exception as e:
+        err = f"{type(e).__name__}: {e}"
+    if not _all_ok(torch, dist, err is None, cdev):
+        return {"workload": label, "error": err or "another rank failed"}
+    dist.barrier()
+    t1 = time.perf_counter()
+    samples = sp.gather_samples(local)
+    dist.barrier()
+    t_gather = time.perf_counter() - t1
+    totals = sp.reduce_counters([sims_done, len(local), local.nbytes])
+    t_play_max, t_gather_max = _max_over_ranks(torch, dist, [t_play, t_gather], cdev)
+    return {"workload": label + f", {sims} sims/move, reference net broadcast from rank 0, eps=0.25, loop resident on each GPU, "
+                        "then gather_samples to rank 0",
+            "value": totals[0] / t_play_max, "unit": "sims/s", "play_s": t_play_max, "games_per_s": games_per_rank * world / t_play_max,
+            "records": int(len(samples)), "records_expected": int(totals[1]), "gather_complete": int(len(samples)) == int(totals[1]),
+            "gathered_bytes": int(samples.nbytes), "gather_s": t_gather_max, "gather_GBps": samples.nbytes / t_gather_max / 1e9}
+
+
+def node_config5(torch, dist, rank, world, dev_index, cdev, games_per_rank, sims=100, shape=SHAPE):
+    """Config 5 on the node: the arena's games sharded over the ranks (two networks, seeds 0 and 1, resident
+    on every GPU, eps 0.25, the networks take turns opening), the tallies summed by reduce_counters."""
+    from alphazero_amd import selfplay as sp
+    from alphazero_amd.evaluator import FusedNetEvaluator
+    from alphazero_amd.model import PolicyValueNet
+
+    label = f"config5: arena, {games_per_rank * world} games of {shape}x{shape} sharded over {world} GPUs"
+    err, tallies, t_play, sims_done = None, (0, 0, 0), 0.0, 0
+    try:
+        dev = torch.device("cuda", dev_index)
+        lo, hi = sp.shard_range(games_per_rank * world, rank, world)
+        nets = []
+        for seed in (0, 1):
+            torch.manual_seed(seed + 10 * rank)
+            nets.append(FusedNetEvaluator(PolicyValueNet(shape).eval(), shape, dev, name=f"seed{seed}"))
+            sp.broadcast_parameters(nets[-1])
+        slots = min(16384, hi - lo)
+        nodes = sims * 3 + 64
+        best = sp.TreeBatch(slots, shape, nets[0], cpuct=CPUCT, eps=0.25, nodes_per_tree=nodes, device=dev_index, noise_seed=2 * rank)
+        latest = sp.TreeBatch(slots, shape, nets[1], cpuct=CPUCT, eps=0.25, nodes_per_tree=nodes, device=dev_index, noise_seed=2 * rank + 1)
+        try:
+            first = ((lo + np.arange(hi - lo)) % (shape * shape)).astype(np.int32)  # distinct first stones by global game index
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            t0 = time.perf_counter()
+            tallies = sp.eval_games_resident(best, latest, sims, sims, n_games=hi - lo, game_openings=first)
+            torch.cuda.synchronize(dev)
+            t_play = time.perf_counter() - t0
+            sims_done = best.eng.get_stats()["sims"] + latest.eng.get_stats()["sims"]
+        finally:
+            best.close()
+            latest.close()
+    except Exception as e:
+        err = f"{type(e).__name__}: {e}"
+    if not _all_ok(torch, dist, err is None, cdev):
+        return {"workload": label, "error": err or "another rank failed"}
+    totals = sp.reduce_counters([sims_done] + [int(x) for x in tallies])
+    (t_play_max,) = _max_over_ranks(torch, dist, [t_play], cdev)
+    return {"workload": label + f", {sims} sims/move, two networks (seeds 0 and 1, broadcast from rank 0), eps=0.25, loop resident on "
+                        "each GPU, tallies by reduce_counters",
+            "value": totals[0] / t_play_max, "unit": "sims/s", "play_s": t_play_max, "games_per_s": games_per_rank * world / t_play_max,
+            "wins_first_net": int(totals[1]), "wins_second_net": int(totals[2]), "draws": int(totals[3]),
+            "games_tallied": int(totals[1] + totals[2] + totals[3])}
+
+
 def stub_rank(args, rank, world, dist):
     """Launcher rehearsal without a GPU (AZ_BENCH_STUB=1): the timing protocol of the real
     bench around a step that only sleeps."""
@@ -525,11 +689,26 @@ def stub_rank(args, rank, world, dist):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(vals, op=dist.ReduceOp.SUM)
         vals[0] = tmax[0]
+    extra = {}
+    if dist is not None:
+        # the node-level blocks of the real bench with made-up data: the census and both exchanges are the real calls
+        from alphazero_amd import selfplay as sp
+
+        cpu = torch.device("cpu")
+        extra.update(rank_census(torch, dist, rank, world, rank, cpu, stub=True))
+        local = np.zeros(rank + 2, sp.sample_dtype(5))
+        local["r"] = rank
+        samples = sp.gather_samples(local, chunk_bytes=500)
+        tallies = sp.reduce_counters([rank + 1, 1, 0])
+        extra["secondary"] = {"config4": {"records": int(len(samples)), "gathered_bytes": int(samples.nbytes), "gather_s": 0.0,
+                                          "gather_complete": int(len(samples)) == sum(r + 2 for r in range(world))},
+                              "config5": {"wins_first_net": int(tallies[0]), "wins_second_net": int(tallies[1]),
+                                          "draws": int(tallies[2])}}
     if rank == 0:
         print(json.dumps({"metric": "stub", "value": float(vals[1] / vals[0]), "unit": "sims/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(vals[0]) / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-                          "data": "synthetic", "config": {"workload": "stub step (launcher rehearsal, no GPU)"}}),
+                          "data": "synthetic", "config": {"workload": "stub step (launcher rehearsal, no GPU)"}, **extra}),
               flush=True)
 
 
@@ -610,14 +789,25 @@ def main():
     total_sims = float(vals[1])
     depth_all = float(vals[2]) / max(1.0, total_sims)
 
+    census, node_secondary = None, None
+    if dist is not None:
+        census = rank_census(torch, dist, rank, world, dev_index, cdev)
+        if not args.no_secondary:
+            g4 = int(os.environ.get("AZ_BENCH_NODE_GAMES4", "8192"))
+            g5 = int(os.environ.get("AZ_BENCH_NODE_GAMES5", "16384"))
+            node_secondary = {"config4": node_config4(torch, dist, rank, world, dev_index, cdev, g4),
+                              "config5": node_config5(torch, dist, rank, world, dev_index, cdev, g5)}
+
     if rank == 0:
         value = total_sims / elapsed
-        roof = tree_roofline(res, B, SHAPE, traffic.get("hbm_bytes_per_launch") if B == TREES else None)
+        roof = tree_roofline(res, B, SHAPE, traffic.get("hbm_bytes_per_launch") if B == TREES else None,
+                             ("profiles/" + traffic["source"]) if B == TREES and "source" in traffic else None)
         roof["note"] = ("frac prices the dense-SoA algorithmic bytes (20 B per child and select) against the HBM peak; "
-                        "hbm_frac is the HBM traffic measured by the TCC counters of the committed profile over the "
-                        "same launch: root statistics stay in registers and fresh nodes hold priors only, so about "
-                        "half the algorithmic bytes reach HBM and the kernel is bound by the instruction stream of "
-                        "one wavefront per SIMD, not by bandwidth")
+                        "design_frac prices the bytes the kernel requests by design (root scans come from registers, a "
+                        "record below the root costs 24 B per padded action, an expansion 8 B); hbm_frac is the HBM traffic "
+                        "the TCC counters measured over the same launch in the committed profile (traffic_source), a "
+                        "constant re-divided by this run's launch time.  About half the algorithmic bytes reach HBM; the "
+                        "kernel is bound by the instruction stream of one wavefront per SIMD, not by bandwidth")
         out = {
             "metric": "MCTS simulations/sec (whole node), 15x15 gomoku @800 sims/move",
             "value": value,
@@ -644,6 +834,10 @@ def main():
             },
             "roofline": roof,
         }
+        if census is not None:  # N > 1: the ranks counted by a collective, their GPUs by PCI address
+            out.update(census)
+        if node_secondary is not None:
+            out["secondary"] = node_secondary
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.warmup, args.steps)
             out["config"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -309,7 +309,7 @@ int az_slots_admit(az_engine *a, az_engine *b, int *d_game_of, int *d_ply, int *
 int az_slots_turn(az_engine *e, const int *d_game_of, const int *d_ply, int by_game, int parity, void *stream);
 /* az_choose_moves for the games in the slots: the sampling limit is the game's own pair
  * index (ply / 2 <= tau samples, src/self_play.py:159-164), the uniform number of a
- * sampled move is a hash of (seed, game, ply) -- mix64(mix64(seed ^ (game << 32 | ply)) +
+ * sampled move is a hash of (seed, game, ply) -- mix64(mix64(mix64(seed) ^ (game << 32 | ply)) +
  * 0x9e3779b97f4a7c15), top 53 bits + 0.5, over 2^53, mix64 = the splitmix64 finaliser -- so
  * a game's moves do not depend on the slot it is played in; tau < 0: always the first
  * maximum (the arena, src/eval.py:192).  d_stage (may be NULL): float [n_trees][max_plies][rec],

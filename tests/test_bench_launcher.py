@@ -30,6 +30,13 @@ def test_plain_invocation_with_two_gpus_launches_two_ranks():
     assert rec["scaling"] == "weak" and rec["higher_is_better"] is True
     # whole-job value: both ranks' work over the slowest rank's time
     assert abs(rec["value"] * rec["ms_per_step"] * 1e-3 * rec["steps"] - 2 * 16 * 800 * 7) < 1e-3 * 2 * 16 * 800 * 7
+    # what an N > 1 line says about the node itself: ranks counted by a collective, one device record per rank,
+    # the sample gather (config 4) and the tally reduction (config 5) as secondary blocks
+    assert rec["rccl_ranks"] == 2 and rec["backend"] == "gloo"
+    assert [d["rank"] for d in rec["devices"]] == [0, 1] and rec["distinct_devices"] == 2
+    c4, c5 = rec["secondary"]["config4"], rec["secondary"]["config5"]
+    assert c4["records"] == 2 + 3 and c4["gather_complete"] is True and c4["gathered_bytes"] == 5 * 304 and "gather_s" in c4
+    assert (c5["wins_first_net"], c5["wins_second_net"], c5["draws"]) == (3, 2, 0)
 
 
 def test_single_rank_stub_needs_no_launcher():

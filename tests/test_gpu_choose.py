@@ -159,7 +159,7 @@ def _mix64(x):
 
 def _u01(seed, row, a, j):
     with np.errstate(over="ignore"):
-        base = _mix64(np.uint64(seed) ^ ((row.astype(np.uint64) << np.uint64(32)) | a.astype(np.uint64)))
+        base = _mix64(_mix64(np.uint64(seed)) ^ ((row.astype(np.uint64) << np.uint64(32)) | a.astype(np.uint64)))
         x = _mix64(base + np.uint64(0x9e3779b97f4a7c15) * (np.asarray(j, np.uint64) + np.uint64(1)))
     return ((x >> np.uint64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
 

@@ -332,6 +332,68 @@ def test_config3_8192_trees_driven_by_the_fused_network():
     batch.close()
 
 
+@pytest.mark.timeout(400)
+def test_config4_share_8192_trees_of_20x20_driven_by_the_fused_network():
+    """One GPU's share of config 4 through the network path: 8192 concurrent 20x20 trees searched by
+    az_simulate_net with the two-wavefront F(4x4,3x3) kernel.  The kernel's outputs at full width on
+    real leaf boards (first step: every root; a later step: leaves two and three levels down, through
+    the position mask) against PyTorch float64, and the bookkeeping invariants on all trees."""
+    import torch
+    from alphazero_amd import selfplay as sp
+
+    G, S, sims, plies = 8192, 20, 16, 3
+    size = S * S
+    net, ev = _fused(S, seed=0)
+    net64 = net.double().to("cuda")
+    batch = sp.TreeBatch(G, S, ev, cpuct=4.0, eps=0.25, nodes_per_tree=160, noise_seed=1)
+    eng = batch.eng
+    for ply in range(2):
+        batch.make_move(np.array([O.opening(size, g)[ply] for g in range(G)], np.int32))
+    stream = torch.cuda.current_stream(batch.dev).cuda_stream
+    batch._ensure_noise(sims)
+    eng.set_active(None)
+    eng.begin_simulate(stream)
+    idx = torch.from_numpy(np.linspace(0, G - 1, 96).astype(np.int64)).to(batch.dev)
+
+    def check_step(expect_all):
+        eng.select(batch.boards.data_ptr(), batch.kinds.data_ptr(), stream)
+        value, logp = ev(batch.boards, batch.kinds)
+        expand = batch.kinds == 1
+        assert int(expand.sum()) == G if expect_all else int(expand.sum()) > G // 2
+        pick = idx[expand[idx]]
+        with torch.no_grad():
+            v64, lp64 = net64(batch.boards[pick].double())
+        np.testing.assert_allclose(value[pick].cpu().numpy(), v64.reshape(-1).cpu().numpy(), rtol=0, atol=2e-5)
+        np.testing.assert_allclose(logp[pick].cpu().numpy(), lp64.reshape(len(pick), -1).cpu().numpy(), rtol=0, atol=2e-5)
+        eng.expand_backup(value.data_ptr(), logp.data_ptr(), True, stream)
+        eng.sync_check(stream)
+        return len(pick)
+
+    assert check_step(True) == 96  # every fresh root is a leaf to expand
+    for _ in range(5):
+        checked = check_step(False)  # leaves below the root
+    assert checked > 48
+    carried = np.full(G, 5, np.int64)  # nodeN the root brings along: the five searches above (its own expansion counts none)
+    for ply in range(plies):
+        batch.simulate(sims)  # az_simulate_net: k_backup_select + k_net_w43t<20> with the position mask
+        counts, root_n = eng.get_counts()
+        assert np.array_equal(counts.sum(axis=1), root_n)
+        assert np.array_equal(root_n, carried + sims)
+        assert counts.min() >= 0
+        raw = eng.get_raw_boards().reshape(G, 2, size)
+        assert not np.any(counts[(raw[:, 0] + raw[:, 1]) > 0])  # occupied cells are never visited
+        act = counts.argmax(axis=1).astype(np.int32)
+        carried = counts[np.arange(G), act].astype(np.int64) - 1
+        batch.make_move(act)
+    st = eng.get_stats()
+    assert st["sims"] == G * (6 + plies * sims)
+    assert st["expansions"] + st["terminals"] == st["sims"]
+    assert np.all(eng.get_errors() == 0)
+    _, move_cnt, winner = eng.get_states()
+    assert np.all(move_cnt == 2 + plies) and np.all(winner == -1)
+    batch.close()
+
+
 def test_errors_of_several_trees_in_one_launch_stay_until_cleared():
     """Pool exhaustion stops a search half way, so the tree must not be searched again
     before it is cleared; an illegal move leaves its tree intact and is cleared by the report."""

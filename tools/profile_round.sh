@@ -5,6 +5,7 @@
 # Usage: tools/profile_round.sh <tag> [<workload>]
 #   no workload: the headline run (traffic figures go to the top level of profiles/traffic.json)
 #   workload:    a name `bench.py --only` takes, e.g. hash_8192_15 (figures stored under that key)
+# PASSES=traffic: kernel trace + the two HBM counter passes only
 set -e
 tag=${1:-r02}
 wl=${2:-}
@@ -20,6 +21,15 @@ else
 fi
 timeout -k 10 170 rocprofv3 --kernel-trace --stats -d "$out/stats" -o s --output-format csv -- $B > "$out/stats.log" 2>&1
 echo stats done
+if [ "${PASSES:-all}" = "traffic" ]; then  # only the two HBM counters (a secondary workload's roofline.traffic)
+  timeout -s KILL 170 rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" -o p --output-format csv -- $B > "$out/pmc_fetch.log" 2>&1
+  echo fetch done
+  timeout -s KILL 170 rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_write" -o p --output-format csv -- $B > "$out/pmc_write.log" 2>&1
+  echo write done
+  python3 tools/summarize_prof.py "$tag" "$out/stats" "$out/pmc_fetch" "$out/pmc_write"
+  cp profiles/${tag}_kernel_stats.csv profiles/${tag}_pmc.json profiles/traffic.json "$out/" 2>/dev/null || true
+  exit 0
+fi
 timeout -s KILL 170 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY -d "$out/pmc_sq" -o p --output-format csv -- $B > "$out/pmc_sq.log" 2>&1
 echo sq done
 timeout -s KILL 170 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS -d "$out/pmc_sq2" -o p --output-format csv -- $B > "$out/pmc_sq2.log" 2>&1

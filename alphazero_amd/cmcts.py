@@ -145,6 +145,19 @@ class mcts:
         self._eng.set_threads(int(v))
 
     @property
+    def schedule(self):
+        """Not in the reference: how the workers of threads > 1 interleave (engine.WORKERS_CONCURRENT, the
+        default: in lock step, their leaves evaluated together; engine.WORKERS_SEQUENTIAL: one after another)."""
+        return self._eng.get_schedule()
+
+    @schedule.setter
+    def schedule(self, v):
+        try:
+            self._eng.set_schedule(int(v))
+        except _E.EngineError as e:
+            _raise(e)
+
+    @property
     def player(self):
         return self._eng.get_state(0)[0]
 
@@ -231,6 +244,20 @@ class mcts:
         if getattr(ev, "fused_layers", None) is not None:
             try:  # the library's own network kernel: one call queues every step of the search
                 self._eng.simulate_net(n, ev.params.data_ptr(), ev.fused_layers, stream)
+            except _E.EngineError as e:
+                _raise(e)
+            return
+        if th_num > 1 and self._eng.get_schedule() == _E.WORKERS_CONCURRENT:
+            wb = torch.zeros((th_num, 2, self._shape, self._shape), dtype=torch.float32, device=dev)
+            wk = torch.zeros(th_num, dtype=torch.int32, device=dev)
+            try:  # the workers in lock step: their th_num leaves in one evaluator call
+                with torch.no_grad():
+                    self._eng.begin_simulate(stream)
+                    for _ in range(per):
+                        self._eng.select_workers(th_num, wb.data_ptr(), wk.data_ptr(), stream)
+                        value, logp = ev(wb)
+                        self._eng.expand_backup_workers(th_num, value.data_ptr(), logp.data_ptr(), ev.log_priors, stream)
+                self._eng.sync_check(stream)
             except _E.EngineError as e:
                 _raise(e)
             return

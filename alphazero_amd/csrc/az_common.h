@@ -49,7 +49,22 @@ struct AzTree {
     int leaf_kind;   // AZ_LEAF_* of the pending step (select -> expand_backup)
     int path_len;    // depth of the pending step's path
     float leaf_value;// value of a terminal leaf of the pending step
+    int flags;       // AZ_TREE_*
     unsigned long long stats[4]; // sims, expansions, terminals, select calls
+};
+// A node of this tree carries a visit deficit (aux[slot] > 0): several concurrent workers met in it while it
+// was unexpanded, so the visits of its parent's action exceed its own nodeN by more than the one that created it.
+#define AZ_TREE_DEFICIT 1
+
+// One concurrent worker of a tree (the reference's std::thread of cmcts.cpp:98-119) between the select and the
+// backup of its search: what AzTree's leaf_kind / path_len / leaf_value / noise_row are for the single worker.
+struct AzWorker {
+    int leaf_kind;    // AZ_LEAF_* of the pending search
+    int path_len;
+    float leaf_value; // value of a finished game
+    int noise_row;    // next row of the worker's own noise stream (restarts per simulate call)
+    int leaf_slot;    // node to expand: its slot, -1 = the root
+    int pad[3];
 };
 
 struct AzParams {
@@ -61,6 +76,14 @@ struct AzParams {
     unsigned *rows;
     int *path_node;   // [n_trees][path_cap] slots along the pending path
     int *path_act;    // [n_trees][path_cap]
+    // aux[t*cap+i]: >= 0: the node's visit deficit (nodeN = N_parent[a] - 1 - deficit; 0 unless concurrent workers met
+    // in the node before it was expanded); < 0: the node was created by a worker of the running step and is not
+    // expanded yet, -aux - 1 further workers have arrived at it since.  0 for free slots.
+    int *aux;
+    AzWorker *workers; // [n_trees][max_workers], null until az_set_threads asks for concurrent workers
+    int *wpath_node;   // [n_trees][max_workers][path_cap]
+    int *wpath_act;
+    int max_workers;
     unsigned long long *stamps; // diagnostic builds only (AZ_STAMPS): [n_trees][8] cycle sums, else null
     const double *noise; // [noise_rows][SP] or null
     int noise_rows;
@@ -109,6 +132,14 @@ struct AzShapeOps {
                         float *d_board, void *stream);
     int (*dirichlet)(double *d_table, int rows, double alpha, unsigned long long seed, void *stream);
     int (*restart)(const AzParams &, const int *d_openings, int n_plies, int *d_count, void *stream);
+    // One step of `nw` concurrent workers per tree (lock-step schedule of the thread fan-out, cmcts.cpp:98-119):
+    // the workers' selects in worker order (position tree * nw + w of d_boards / d_leaf_kind / the masks), and the
+    // workers' expand + backup in worker order; the third is the backups of a step and the selects of the next.
+    int (*workers_select)(const AzParams &, int nw, float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask,
+                          unsigned *d_clear_mask, void *stream);
+    int (*workers_backup)(const AzParams &, int nw, const float *d_value, const float *d_prior, int prior_is_log, void *stream);
+    int (*workers_backup_select)(const AzParams &, int nw, const float *d_value, const float *d_prior, int prior_is_log,
+                                 float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask, unsigned *d_clear_mask, void *stream);
     // choose_moves with the record fields written to row d_ply[tree] of the tree's staging rows:
     // d_stage + tree * max_plies * rec + d_ply[tree] * rec, rec = 3 * SIZE + 1 (board, pi, r)
     int (*choose_moves_staged)(const AzParams &, const double *d_u, int *d_actions, float *d_stage, int max_plies,

@@ -70,6 +70,7 @@ struct az_engine {
     AzParams P{};
     double alpha = 1.0;
     int threads = 0;
+    int schedule = AZ_WORKERS_CONCURRENT; // how az_simulate_net runs the workers of threads > 1
     int cuda = 0;
     unsigned long long device_bytes = 0;
     // device scratch
@@ -80,6 +81,7 @@ struct az_engine {
     double *d_noise = nullptr;     // [rows][sp]
     int noise_cap = 0;             // rows allocated at d_noise
     char *d_stage = nullptr;       // az_simulate_net: leaf boards, codes, values, log-priors of one step
+    size_t stage_bytes = 0;
     double *d_u = nullptr;         // [n_trees] az_slots_choose: the uniform number of each slot's move
     int *d_emit = nullptr;         // [3][n_trees] az_slots_finish: first record, record count and game of the slots that finish
     std::vector<AzTree> h_trees;
@@ -172,7 +174,8 @@ const char *kernel_err_text(int code)
     case AZ_ERR_NOISE_ROWS: return "noise table exhausted";
     case AZ_ERR_INVALID_MOVE: return "Invalid move";
     case AZ_ERR_NOT_DIST: return "Not a distribution";
-    case AZ_ERR_STATE: return "record row outside the staging rows";
+    case AZ_ERR_STATE: return "the tree's state does not allow this call (a record row outside the staging rows, or az_simulate_fused "
+                              "on a tree whose nodes carry visit deficits from concurrent workers)";
     default: return "kernel error";
     }
 }
@@ -240,6 +243,10 @@ int az_create(az_engine **out, int device, int n_trees, int shape, int nodes_per
     if (!rc) rc = dev_alloc(e, &P.rows, (size_t)n_trees * 64);
     if (!rc) rc = dev_alloc(e, &P.path_node, (size_t)n_trees * P.path_cap);
     if (!rc) rc = dev_alloc(e, &P.path_act, (size_t)n_trees * P.path_cap);
+    if (!rc) rc = dev_alloc(e, &P.aux, slots);
+    P.workers = nullptr;
+    P.wpath_node = P.wpath_act = nullptr;
+    P.max_workers = 0;
     if (!rc) rc = dev_alloc(e, &e->d_actions, (size_t)n_trees);
     if (!rc) rc = dev_alloc(e, &e->d_mask, (size_t)n_trees);
     if (!rc) rc = dev_alloc(e, &e->d_counts, (size_t)n_trees * e->size);
@@ -259,6 +266,7 @@ int az_create(az_engine **out, int device, int n_trees, int shape, int nodes_per
         hipError_t he = hipMemcpy(P.free_stack, stack.data(), slots * sizeof(int), hipMemcpyHostToDevice);
         if (he == hipSuccess) he = hipMemcpy(P.parent, par.data(), slots * sizeof(int), hipMemcpyHostToDevice);
         if (he == hipSuccess) he = hipMemset(P.rows, 0, (size_t)n_trees * 64 * sizeof(unsigned));
+        if (he == hipSuccess) he = hipMemset(P.aux, 0, slots * sizeof(int));
         e->h_trees.assign(n_trees, AzTree{});
         for (auto &t : e->h_trees) {
             t.root = -1;
@@ -288,7 +296,7 @@ void az_destroy(az_engine *e)
     (void)hipStreamSynchronize(nullptr);
     AzParams &P = e->P;
     void *ptrs[] = {P.nodes, P.parent, P.free_stack, P.order, P.trees, P.rows,
-                    P.path_node, P.path_act, P.stamps, e->d_actions, e->d_mask, e->d_counts, e->d_root_n, e->d_noise, e->d_stage,
+                    P.path_node, P.path_act, P.aux, P.workers, P.wpath_node, P.wpath_act, P.stamps, e->d_actions, e->d_mask, e->d_counts, e->d_root_n, e->d_noise, e->d_stage,
                     e->d_u, e->d_emit};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -335,12 +343,46 @@ int az_set_alpha_default(az_engine *e)
     e->alpha = 10 / num;
     return AZ_OK;
 }
+// per-worker state for `workers` concurrent workers per tree (grows only; the search entry points never allocate it)
+static int ensure_workers(az_engine *e, int workers)
+{
+    if (workers <= e->P.max_workers) return AZ_OK;
+    if (workers > AZ_MAX_WORKERS) return fail(AZ_ERR_ARG, "at most %d concurrent workers per tree", AZ_MAX_WORKERS);
+    DeviceGuard g(e->device);
+    if (int rc = wait_queued(e)) return rc;
+    void *old[] = {e->P.workers, e->P.wpath_node, e->P.wpath_act};
+    for (void *p : old)
+        if (p) (void)hipFree(p);
+    e->P.workers = nullptr;
+    e->P.wpath_node = e->P.wpath_act = nullptr;
+    e->P.max_workers = 0;
+    const size_t n = (size_t)e->n_trees * workers;
+    if (int rc = dev_alloc(e, &e->P.workers, n)) return rc;
+    if (int rc = dev_alloc(e, &e->P.wpath_node, n * e->P.path_cap)) return rc;
+    if (int rc = dev_alloc(e, &e->P.wpath_act, n * e->P.path_cap)) return rc;
+    HIP_TRY(hipMemset(e->P.workers, 0, n * sizeof(AzWorker)));
+    e->P.max_workers = workers;
+    return AZ_OK;
+}
+
 int az_set_threads(az_engine *e, int threads)
 {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
+    if (threads > 1 && e->schedule == AZ_WORKERS_CONCURRENT)
+        if (int rc = ensure_workers(e, threads)) return rc;
     e->threads = threads;
     return AZ_OK;
 }
+int az_set_schedule(az_engine *e, int schedule)
+{
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    if (schedule != AZ_WORKERS_SEQUENTIAL && schedule != AZ_WORKERS_CONCURRENT) return fail(AZ_ERR_ARG, "unknown schedule %d", schedule);
+    if (schedule == AZ_WORKERS_CONCURRENT && e->threads > 1)
+        if (int rc = ensure_workers(e, e->threads)) return rc;
+    e->schedule = schedule;
+    return AZ_OK;
+}
+int az_get_schedule(const az_engine *e) { return e ? e->schedule : 0; }
 int az_get_threads(const az_engine *e) { return e->threads; }
 int az_set_cuda(az_engine *e, int cuda)
 {
@@ -514,6 +556,39 @@ int az_begin_simulate(az_engine *e, void *stream)
     // noise_row := 0 for every tree: a strided 4-byte memset
     HIP_TRY(hipMemset2DAsync((char *)e->P.trees + offsetof(AzTree, noise_row), sizeof(AzTree), 0, sizeof(int),
                              e->n_trees, (hipStream_t)stream));
+    if (e->P.workers) // every concurrent worker builds a generator of its own (cmcts.cpp:132-133)
+        HIP_TRY(hipMemset2DAsync((char *)e->P.workers + offsetof(AzWorker, noise_row), sizeof(AzWorker), 0, sizeof(int),
+                                 (size_t)e->n_trees * e->P.max_workers, (hipStream_t)stream));
+    note_queued(e, stream);
+    return AZ_OK;
+}
+
+static int check_workers(const az_engine *e, int n_workers)
+{
+    if (n_workers < 1 || n_workers > e->P.max_workers)
+        return fail(AZ_ERR_ARG, "n_workers must be in 1..%d (az_set_threads with the concurrent schedule sets the limit)",
+                    e->P.max_workers);
+    return AZ_OK;
+}
+
+int az_select_workers(az_engine *e, int n_workers, float *d_boards, int *d_leaf_kind, void *stream)
+{
+    if (!e || !d_boards || !d_leaf_kind) return fail(AZ_ERR_ARG, "null argument");
+    if (int rc = check_workers(e, n_workers)) return rc;
+    DeviceGuard g(e->device);
+    if (e->ops->workers_select(e->P, n_workers, d_boards, d_leaf_kind, nullptr, nullptr, stream))
+        return fail(AZ_ERR_HIP, "workers_select launch failed");
+    note_queued(e, stream);
+    return AZ_OK;
+}
+
+int az_expand_backup_workers(az_engine *e, int n_workers, const float *d_value, const float *d_prior, int prior_is_log, void *stream)
+{
+    if (!e || !d_value || !d_prior) return fail(AZ_ERR_ARG, "null argument");
+    if (int rc = check_workers(e, n_workers)) return rc;
+    DeviceGuard g(e->device);
+    if (e->ops->workers_backup(e->P, n_workers, d_value, d_prior, prior_is_log, stream))
+        return fail(AZ_ERR_HIP, "workers_backup launch failed");
     note_queued(e, stream);
     return AZ_OK;
 }
@@ -564,15 +639,7 @@ static StageLayout stage_layout(int n, int size)
 static int simulate_net_steps(az_engine *e, int n, const float *d_params, int front, int pol, int val, char *stage,
                               void *stream)
 {
-    const StageLayout L = stage_layout(e->n_trees, e->size);
-    float *boards = reinterpret_cast<float *>(stage + L.boards);
-    float *logp = reinterpret_cast<float *>(stage + L.logp);
-    float *value = reinterpret_cast<float *>(stage + L.value);
-    int *kinds = reinterpret_cast<int *>(stage + L.kinds);
-    unsigned *mask[2] = {reinterpret_cast<unsigned *>(stage + L.mask[0]), reinterpret_cast<unsigned *>(stage + L.mask[1])};
-    HIP_TRY(hipMemsetAsync(stage + L.mask[0], 0, 2 * L.mask_bytes, (hipStream_t)stream));
-    int step = 0;
-    // thread fan-out of cmcts.cpp:98-119: th_num workers of `per` searches, one after another
+    // thread fan-out of cmcts.cpp:98-119: th_num workers of `per` searches
     int th_num = 1, per = n;
     if (e->threads > 1) {
         th_num = e->threads;
@@ -580,6 +647,39 @@ static int simulate_net_steps(az_engine *e, int n, const float *d_params, int fr
         else if (n % th_num == 0) per = n / th_num;
         else per = n / th_num + 1;
     }
+    const bool concurrent = th_num > 1 && e->schedule == AZ_WORKERS_CONCURRENT;
+    const StageLayout L = stage_layout(e->n_trees * (concurrent ? th_num : 1), e->size);
+    float *boards = reinterpret_cast<float *>(stage + L.boards);
+    float *logp = reinterpret_cast<float *>(stage + L.logp);
+    float *value = reinterpret_cast<float *>(stage + L.value);
+    int *kinds = reinterpret_cast<int *>(stage + L.kinds);
+    unsigned *mask[2] = {reinterpret_cast<unsigned *>(stage + L.mask[0]), reinterpret_cast<unsigned *>(stage + L.mask[1])};
+    HIP_TRY(hipMemsetAsync(stage + L.mask[0], 0, 2 * L.mask_bytes, (hipStream_t)stream));
+    int step = 0;
+    if (concurrent) {
+        // the workers in lock step: per step their th_num selects per tree, ONE evaluation of all th_num * n_trees
+        // leaves, their th_num backups; the backups of a step and the selects of the next share a launch
+        if (int rc = check_workers(e, th_num)) return rc;
+        HIP_TRY(hipMemset2DAsync((char *)e->P.workers + offsetof(AzWorker, noise_row), sizeof(AzWorker), 0, sizeof(int),
+                                 (size_t)e->n_trees * e->P.max_workers, (hipStream_t)stream));
+        const int n_pos = e->n_trees * th_num;
+        if (e->ops->workers_select(e->P, th_num, boards, kinds, mask[0], mask[1], stream))
+            return fail(AZ_ERR_HIP, "workers_select launch failed");
+        for (int i = 0; i < per; i++) {
+            unsigned *cur = mask[step & 1], *other = mask[(step + 1) & 1];
+            step++;
+            if (int rc = az_net_eval_masked(e->shape, n_pos, boards, kinds, cur, d_params, front, pol, val, value, logp, stream))
+                return fail(rc, "network evaluation launch failed");
+            if (i + 1 < per) {
+                if (e->ops->workers_backup_select(e->P, th_num, value, logp, 1, boards, kinds, other, cur, stream))
+                    return fail(AZ_ERR_HIP, "workers_backup_select launch failed");
+            } else if (e->ops->workers_backup(e->P, th_num, value, logp, 1, stream)) {
+                return fail(AZ_ERR_HIP, "workers_backup launch failed");
+            }
+        }
+        return AZ_OK;
+    }
+    // sequential schedule: the workers one after another
     // At most one tree per CU: the launches of a search step would cost more than their work, so the whole
     // call is one launch (k_net_search; same arithmetic).  AZ_NET_SEARCH=0 in the environment, or a kernel
     // form forced through az_net_set_form, keeps the stepped launches.
@@ -587,7 +687,7 @@ static int simulate_net_steps(az_engine *e, int n, const float *d_params, int fr
         int cus = 0;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device);
         const char *sw = getenv("AZ_NET_SEARCH");
-        if (e->n_trees <= cus && az_net_get_form() == AZ_NET_FORM_AUTO && !(sw && atoi(sw) == 0)) {
+        if (!concurrent && e->n_trees <= cus && az_net_get_form() == AZ_NET_FORM_AUTO && !(sw && atoi(sw) == 0)) {
             if (e->ops->net_search(e->P, th_num, per, d_params, front, pol, val, stream))
                 return fail(AZ_ERR_HIP, "net_search launch failed");
             return AZ_OK;
@@ -626,9 +726,18 @@ int az_simulate_net(az_engine *e, int n, const float *d_params, int front_layers
         return fail(AZ_ERR_NO_PREDICTOR, "Predictor missing!");
     if (int rc = check_noise(e)) return rc;
     DeviceGuard g(e->device);
-    if (!e->d_stage) {
-        const StageLayout L = stage_layout(e->n_trees, e->size);
+    const int width = e->threads > 1 && e->schedule == AZ_WORKERS_CONCURRENT ? e->threads : 1; // leaves per tree and step
+    const StageLayout L = stage_layout(e->n_trees * width, e->size);
+    if (!e->d_stage || L.bytes > e->stage_bytes) {
+        if (e->d_stage) {
+            if (int rc = wait_queued(e)) return rc;
+            (void)hipFree(e->d_stage);
+            e->device_bytes -= e->stage_bytes;
+            e->d_stage = nullptr;
+            e->stage_bytes = 0;
+        }
         HIP_TRY(hipMalloc((void **)&e->d_stage, L.bytes));
+        e->stage_bytes = L.bytes;
         e->device_bytes += L.bytes;
     }
     const int rc = simulate_net_steps(e, n, d_params, front_layers, policy_layers, value_layers, e->d_stage, stream);
@@ -644,9 +753,10 @@ int az_simulate_net_noalloc(az_engine *e, int n, const float *d_params, int fron
     if (!d_params || az_net_param_floats(front_layers, policy_layers, value_layers) == 0)
         return fail(AZ_ERR_NO_PREDICTOR, "Predictor missing!");
     if (int rc = check_noise(e)) return rc;
-    const StageLayout L = stage_layout(e->n_trees, e->size);
+    const int width = e->threads > 1 && e->schedule == AZ_WORKERS_CONCURRENT ? e->threads : 1; // leaves per tree and step
+    const StageLayout L = stage_layout(e->n_trees * width, e->size);
     if (L.bytes > AZ_NOALLOC_SCRATCH_BYTES) {
-        const size_t per_tree = (size_t)(3 * e->size + 2) * 4;
+        const size_t per_tree = (size_t)(3 * e->size + 2) * 4 * width;
         return fail(AZ_ERR_ARG,
                     "az_simulate_net_noalloc: %d trees of %dx%d need %zu bytes of step staging, the fixed buffer "
                     "holds %u (about %zu trees of this shape); use az_simulate_net",
@@ -941,7 +1051,9 @@ int az_get_node(az_engine *e, int tree, const int *path, int len, int *found, in
         HIP_TRY(hipMemcpy(&cnt, rec + (size_t)path[i] * 4, sizeof(int), hipMemcpyDeviceToHost));
         if (link == 0) return AZ_OK;
         slot = link - 1;
-        nn = cnt - 1; // the first visit of the action created the child
+        int deficit = 0; // visits of the action by concurrent workers that met in the unexpanded child (AzParams::aux)
+        HIP_TRY(hipMemcpy(&deficit, e->P.aux + (size_t)tree * e->cap + slot, sizeof(int), hipMemcpyDeviceToHost));
+        nn = cnt - 1 - (deficit > 0 ? deficit : 0); // the first visit of the action created the child
     }
     const bool fresh = nn == 0 && len > 0; // statistics not materialised yet: implicit zeros
     std::vector<int> n;

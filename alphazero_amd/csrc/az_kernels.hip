@@ -783,6 +783,12 @@ __global__ __launch_bounds__(64 * WPT) AZ_FUSED_ATTR void k_simulate_fused(AzPar
     const int tid = threadIdx.x;
     AzTree *Tr = &P.trees[tree];
     if (uni(Tr->active) == 0 || uni(Tr->err) != 0) return;
+    // A tree whose nodes carry visit deficits (left by concurrent workers, see AzParams::aux) is not searched here:
+    // this kernel derives every node's nodeN from its parent's visit count alone.
+    if (AZ_UNLIKELY((uni(Tr->flags) & AZ_TREE_DEFICIT) != 0)) {
+        if (tid == 0) Tr->err = AZ_ERR_STATE;
+        return;
+    }
 
     // overflow of the register-resident path (depth > 64); every wavefront
     // writes the same values
@@ -1116,6 +1122,7 @@ __device__ __forceinline__ void select_body(const AzParams &P, int tree, int out
     int depth = 0, kind = AZ_LEAF_EXPAND, err = 0, phase = 0;
     float leaf_value = 0.f;
     unsigned long long n_sel = 0;
+    const bool deficits = (uni(T->flags) & AZ_TREE_DEFICIT) != 0; // (rare: left by concurrent workers)
     while (cur >= 0) {
         const bool fresh = nn == 0 && cur != root; // a root is always materialised
         NodeRegs<E> nd;
@@ -1147,6 +1154,7 @@ __device__ __forceinline__ void select_body(const AzParams &P, int tree, int out
         }
         cur = pk.link - 1; // -1 ends the walk: the child does not exist yet
         nn = pk.n - 1;
+        if (AZ_UNLIKELY(deficits) && cur >= 0) nn -= uni(P.aux[(size_t)tree * P.cap + cur]);
     }
     if (err) kind = AZ_LEAF_NONE;
     if (kind == AZ_LEAF_EXPAND) write_board(s, d_boards + (size_t)out * 2 * SIZE, lane);
@@ -1274,6 +1282,225 @@ __global__ __launch_bounds__(64) AZ_STEP_OCC void k_backup_select(AzParams P, co
     select_body(P, blockIdx.x, blockIdx.x, threadIdx.x, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
 }
 
+// ------------------------------------------------ concurrent workers, lock step
+// threads > 1 in the reference (cmcts.cpp:98-119): T std::threads search one tree at once, kept apart by the
+// virtual loss (node.cpp:115-118); how they interleave is up to the OS.  Here they advance in lock step, which
+// is one legal interleaving: per step the workers 0..T-1, in that order, descend to their leaf (k_workers_select:
+// every visit and virtual loss is stored at once, so a later worker of the step sees it), the T leaves of every
+// tree are evaluated in ONE batch, and the workers finish in the same order (k_workers_backup: set_prior, which
+// does nothing when an earlier worker of the step expanded the same node, node.cpp:30-33; backup).
+// Node::next_node (node.cpp:126-134) creates the child during the DESCENT, so a later worker of the same step can
+// arrive at a node that exists but is not expanded: such a node is marked in AzParams::aux (see az_common.h); the
+// workers that meet there all count a visit of the parent's action, none of them selects from the child, and the
+// surplus is kept as the child's visit deficit once it is expanded.
+__device__ __forceinline__ void wselect_body(const AzParams &P, int tree, int w, int nw, int lane, const WState &root_state,
+                                             float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask, unsigned *d_clear_mask)
+{
+    constexpr int E = EPL;
+    AzTree *T = &P.trees[tree];
+    AzWorker *W = &P.workers[(size_t)tree * P.max_workers + w];
+    const int out = tree * nw + w;
+    if (d_clear_mask != nullptr && lane == 0 && (out & 31) == 0) d_clear_mask[(out >> 5) * AZ_MASK_STRIDE] = 0u;
+    if (uni(T->active) == 0 || uni(T->err) != 0) { // (an error raised by an earlier worker of this step stops the others too)
+        if (lane == 0) { W->leaf_kind = AZ_LEAF_NONE; d_leaf_kind[out] = AZ_LEAF_NONE; }
+        return;
+    }
+    const size_t tbase = (size_t)tree * P.cap;
+    int *pn = P.wpath_node + ((size_t)tree * P.max_workers + w) * P.path_cap;
+    int *pa = P.wpath_act + ((size_t)tree * P.max_workers + w) * P.path_cap;
+    WState s = root_state;
+    const int root = uni(T->root);
+    int cur = root;
+    int nn = root >= 0 ? uni(T->root_n) : 0;
+    int depth = 0, kind = AZ_LEAF_EXPAND, err = 0, phase = 0, leaf_slot = -1;
+    float leaf_value = 0.f;
+    unsigned long long n_sel = 0;
+    while (cur >= 0) {
+        const bool fresh = nn == 0 && cur != root; // a root is always materialised
+        NodeRegs<E> nd;
+        load_node<E>(P, tree, cur, lane, fresh, nd);
+        const Pick pk = select_pick<1, E>(nd, fresh, sqrt_node_n(nn, nullptr), s.occ, P.cpuct, lane, nullptr, phase);
+        if (pk.a < 0) { err = AZ_ERR_NO_ACTION; break; }
+        n_sel++;
+        char *rec = rec_ptr(P, tree, cur);
+        if (fresh) {
+#pragma unroll
+            for (int k = 0; k < E; k++)
+                if (lane == owner_of<E>(pk.a) && k == slot_of<E>(pk.a)) { nd.n[k] = 1; nd.w[k] = -1.; }
+            store_stats<E>(P, tree, cur, lane, nd);
+        } else if (lane == owner_of<E>(pk.a)) {
+            reinterpret_cast<int *>(rec + OFF_N)[pk.a] = pk.n + 1;
+            reinterpret_cast<double *>(rec + OFF_W)[pk.a] = pk.w - 1.;
+        }
+        if (lane == 0) {
+            if (cur == root) T->root_n = nn + 1;
+            pn[depth] = cur;
+            pa[depth] = pk.a;
+        }
+        depth++;
+        state_move<E>(s, pk.a, lane);
+        if (s.winner != -1.f) {
+            kind = AZ_LEAF_TERMINAL;
+            leaf_value = (s.winner == 0.f || s.winner == 1.f) ? 1.f : 0.f;
+            break;
+        }
+        if (pk.link == 0) { // Node::next_node creates the child now (node.cpp:126-134); this worker will expand it
+            const int free_top = uni(T->free_top);
+            if (free_top == 0) { err = AZ_ERR_POOL_FULL; break; }
+            const int n_order = uni(T->n_order);
+            const int slot = uni(P.free_stack[tbase + free_top - 1]);
+            if (lane == owner_of<E>(pk.a)) reinterpret_cast<int *>(rec + OFF_LINK)[pk.a] = slot + 1;
+            if (lane == 0) {
+                P.parent[tbase + slot] = cur;
+                P.order[tbase + n_order] = slot;
+                P.aux[tbase + slot] = -1;
+                T->free_top = free_top - 1;
+                T->n_order = n_order + 1;
+            }
+            leaf_slot = slot;
+            break;
+        }
+        const int child = pk.link - 1;
+        const int ax = uni(P.aux[tbase + child]);
+        if (ax < 0) { // created by an earlier worker of this step and not expanded yet: the leaf of this worker too
+            if (lane == 0) P.aux[tbase + child] = ax - 1;
+            leaf_slot = child;
+            break;
+        }
+        cur = child;
+        nn = pk.n - 1 - ax;
+    }
+    if (err) kind = AZ_LEAF_NONE;
+    if (kind == AZ_LEAF_EXPAND) write_board(s, d_boards + (size_t)out * 2 * SIZE, lane);
+    if (lane == 0) {
+        W->leaf_kind = kind;
+        W->path_len = depth;
+        W->leaf_value = leaf_value;
+        W->leaf_slot = leaf_slot;
+        T->stats[3] += n_sel;
+        if (err) T->err = err;
+        d_leaf_kind[out] = kind;
+        if (d_expand_mask != nullptr && kind == AZ_LEAF_EXPAND) atomicOr(&d_expand_mask[(out >> 5) * AZ_MASK_STRIDE], 1u << (out & 31));
+    }
+}
+
+__device__ __forceinline__ void wbackup_body(const AzParams &P, int tree, int w, int nw, int lane, const float *d_value,
+                                             const float *d_prior, int prior_is_log)
+{
+    constexpr int E = EPL;
+    AzTree *T = &P.trees[tree];
+    AzWorker *W = &P.workers[(size_t)tree * P.max_workers + w];
+    const int kind = uni(W->leaf_kind);
+    if (kind == AZ_LEAF_NONE) return;
+    if (uni(T->err) != 0) { // an earlier worker of this step failed: the tree is left as it is (no backup either)
+        if (lane == 0) W->leaf_kind = AZ_LEAF_NONE;
+        return;
+    }
+    const int out = tree * nw + w;
+    const size_t tbase = (size_t)tree * P.cap;
+    const int *pn = P.wpath_node + ((size_t)tree * P.max_workers + w) * P.path_cap;
+    const int *pa = P.wpath_act + ((size_t)tree * P.max_workers + w) * P.path_cap;
+    const int depth = uni(W->path_len);
+    float value;
+    if (kind == AZ_LEAF_EXPAND) {
+        const int leaf_slot = uni(W->leaf_slot);
+        int slot = leaf_slot, ax = 0, err = 0;
+        bool expand, is_root = leaf_slot < 0;
+        int free_top = 0, n_order = 0;
+        if (is_root) {
+            expand = uni(T->root) < 0; // else an earlier worker of this step has expanded the root
+            if (expand) {
+                free_top = uni(T->free_top);
+                n_order = uni(T->n_order);
+                if (free_top == 0) err = AZ_ERR_POOL_FULL;
+                else slot = uni(P.free_stack[tbase + free_top - 1]);
+            }
+        } else {
+            ax = uni(P.aux[tbase + leaf_slot]);
+            expand = ax < 0; // else expanded by the worker that created it (node.cpp:30-33: nothing to do)
+        }
+        const int noise_row = uni(W->noise_row);
+        if (expand && !err && P.noise != nullptr && noise_row >= P.noise_rows) err = AZ_ERR_NOISE_ROWS;
+        if (err) {
+            if (lane == 0) { T->err = err; W->leaf_kind = AZ_LEAF_NONE; }
+            return;
+        }
+        if (expand) {
+            float pr[E];
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                const int a = lane * E + k;
+                pr[k] = a < SIZE ? d_prior[(size_t)out * SIZE + a] : 0.f;
+            }
+            NodeRegs<E> nd;
+            mix_prior<E>(P, pr, prior_is_log != 0, noise_row, lane, nd.p);
+            st_f64<E>(rec_ptr(P, tree, slot), OFF_P, lane, nd.p);
+            if (is_root) { // the root is always materialised
+#pragma unroll
+                for (int k = 0; k < E; k++) { nd.n[k] = 0; nd.link[k] = 0; nd.w[k] = 0.; }
+                store_stats<E>(P, tree, slot, lane, nd);
+            }
+            if (lane == 0) {
+                if (is_root) {
+                    T->root = slot;
+                    T->root_n = 0;
+                    P.parent[tbase + slot] = -1;
+                    P.order[tbase + n_order] = slot;
+                    P.aux[tbase + slot] = 0;
+                    T->free_top = free_top - 1;
+                    T->n_order = n_order + 1;
+                } else {
+                    const int extra = -ax - 1; // workers that arrived after the one that created the node
+                    P.aux[tbase + slot] = extra;
+                    if (extra > 0) T->flags = T->flags | AZ_TREE_DEFICIT;
+                }
+                if (P.noise != nullptr) W->noise_row = noise_row + 1;
+                T->stats[1] += 1;
+            }
+        }
+        value = -d_value[out]; // cmcts.cpp:228
+    } else {
+        value = unif(W->leaf_value);
+        if (lane == 0) T->stats[2] += 1;
+    }
+    for (int d = 0; d < depth; d++) {
+        const int node = uni(pn[d]), act = uni(pa[d]);
+        if (lane == owner_of<E>(act)) {
+            const float vd = ((depth - 1 - d) & 1) ? -value : value;
+            double *wp = reinterpret_cast<double *>(rec_ptr(P, tree, node) + OFF_W) + act;
+            *wp += (double)vd + 1.; // node.cpp:80
+        }
+    }
+    if (lane == 0) {
+        W->leaf_kind = AZ_LEAF_NONE;
+        T->stats[0] += 1;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_workers_select(AzParams P, int nw, float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask,
+                                                       unsigned *d_clear_mask)
+{
+    const int tree = blockIdx.x, lane = threadIdx.x;
+    WState rs;
+    load_state<EPL>(P, tree, lane, rs);
+    for (int w = 0; w < nw; w++) wselect_body(P, tree, w, nw, lane, rs, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
+}
+__global__ __launch_bounds__(64) void k_workers_backup(AzParams P, int nw, const float *d_value, const float *d_prior, int prior_is_log)
+{
+    const int tree = blockIdx.x, lane = threadIdx.x;
+    for (int w = 0; w < nw; w++) wbackup_body(P, tree, w, nw, lane, d_value, d_prior, prior_is_log);
+}
+__global__ __launch_bounds__(64) void k_workers_backup_select(AzParams P, int nw, const float *d_value, const float *d_prior,
+                                                              int prior_is_log, float *d_boards, int *d_leaf_kind,
+                                                              unsigned *d_expand_mask, unsigned *d_clear_mask)
+{
+    const int tree = blockIdx.x, lane = threadIdx.x;
+    for (int w = 0; w < nw; w++) wbackup_body(P, tree, w, nw, lane, d_value, d_prior, prior_is_log);
+    WState rs;
+    load_state<EPL>(P, tree, lane, rs);
+    for (int w = 0; w < nw; w++) wselect_body(P, tree, w, nw, lane, rs, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
+}
+
 // ------------------------------------------- network search in one launch (few trees)
 // Cmcts::simulate with the reference network (cmcts.cpp:83-282) for batches of at most one tree per CU:
 // ONE launch for all searches of a call instead of two launches per search, whose dispatch gaps are a
@@ -1384,6 +1611,7 @@ __global__ __launch_bounds__(64) void k_make_move(AzParams P, const int *d_actio
         const char *rec = rec_ptr(P, tree, root);
         new_root = uni(reinterpret_cast<const int *>(rec + OFF_LINK)[a]) - 1;
         new_root_n = uni(reinterpret_cast<const int *>(rec + OFF_N)[a]) - 1;
+        if (new_root >= 0) new_root_n -= uni(P.aux[tbase + new_root]); // (0 unless concurrent workers met in it)
     }
     if (new_root >= 0 && new_root_n == 0) { // a never-selected node becomes the root: materialise it
         NodeRegs<E> z;
@@ -1420,6 +1648,7 @@ __global__ __launch_bounds__(64) void k_make_move(AzParams P, const int *d_actio
         if (idx >= 0 && !m) {
             P.free_stack[tbase + free_top + __popcll(dead & lt)] = idx;
             P.parent[tbase + idx] = -2;
+            P.aux[tbase + idx] = 0;
         }
         kept += __popcll(keep);
         free_top += __popcll(dead);
@@ -1450,6 +1679,7 @@ __global__ __launch_bounds__(64) void k_clear(AzParams P, const unsigned char *d
         const int idx = P.order[tbase + i];
         P.free_stack[tbase + free_top + i] = idx;
         P.parent[tbase + idx] = -2;
+        P.aux[tbase + idx] = 0;
     }
     P.rows[tree * 64 + lane] = 0u;
     if (lane == 0) {
@@ -1461,6 +1691,7 @@ __global__ __launch_bounds__(64) void k_clear(AzParams P, const unsigned char *d
         T->move_cnt = 0;
         T->winner = -1.f;
         T->err = 0;
+        T->flags = 0;
         T->noise_row = 0;
         T->leaf_kind = AZ_LEAF_NONE;
         T->path_len = 0;
@@ -1488,6 +1719,7 @@ __global__ __launch_bounds__(64) void k_restart(AzParams P, const int *d_opening
         const int idx = P.order[tbase + i];
         P.free_stack[tbase + free_top + i] = idx;
         P.parent[tbase + idx] = -2;
+        P.aux[tbase + idx] = 0;
     }
     WState s;
     s.rb = 0u; s.occ = 0u; s.player = 0; s.move_cnt = 0; s.winner = -1.f;
@@ -1510,6 +1742,7 @@ __global__ __launch_bounds__(64) void k_restart(AzParams P, const int *d_opening
         T->move_cnt = s.move_cnt;
         T->winner = s.winner;
         T->err = err;
+        T->flags = 0;
         T->noise_row = 0;
         T->leaf_kind = AZ_LEAF_NONE;
         T->path_len = 0;
@@ -1781,6 +2014,25 @@ int l_backup_select(const AzParams &P, const float *d_value, const float *d_prio
                        d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
     return launch_status();
 }
+int l_workers_select(const AzParams &P, int nw, float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask, unsigned *d_clear_mask,
+                     void *stream)
+{
+    hipLaunchKernelGGL(k_workers_select, dim3(P.n_trees), dim3(64), 0, (hipStream_t)stream, P, nw, d_boards, d_leaf_kind,
+                       d_expand_mask, d_clear_mask);
+    return launch_status();
+}
+int l_workers_backup(const AzParams &P, int nw, const float *d_value, const float *d_prior, int is_log, void *stream)
+{
+    hipLaunchKernelGGL(k_workers_backup, dim3(P.n_trees), dim3(64), 0, (hipStream_t)stream, P, nw, d_value, d_prior, is_log);
+    return launch_status();
+}
+int l_workers_backup_select(const AzParams &P, int nw, const float *d_value, const float *d_prior, int is_log, float *d_boards,
+                            int *d_leaf_kind, unsigned *d_expand_mask, unsigned *d_clear_mask, void *stream)
+{
+    hipLaunchKernelGGL(k_workers_backup_select, dim3(P.n_trees), dim3(64), 0, (hipStream_t)stream, P, nw, d_value, d_prior, is_log,
+                       d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
+    return launch_status();
+}
 int l_net_search(const AzParams &P, int th_num, int per, const float *d_params, int front, int pol, int val, void *stream)
 {
     const size_t lds_bytes = (size_t)NET_SEARCH_LDS_FLOATS * sizeof(float);
@@ -1858,7 +2110,7 @@ extern "C" const AzShapeOps *AZ_CAT(az_shape_ops_, AZ_S)(void)
 {
     static const AzShapeOps ops = {
         AZ_S, SP, l_simulate_fused, l_select, l_expand_backup, l_backup_select, l_net_search, l_make_move, l_clear, l_select_greedy, l_get_counts,
-        l_choose_moves, l_dirichlet, l_restart, l_choose_moves_staged,
+        l_choose_moves, l_dirichlet, l_restart, l_workers_select, l_workers_backup, l_workers_backup_select, l_choose_moves_staged,
     };
     return &ops;
 }

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AZ_LIBAZMCTS") or os.path.join(_HERE, "libazmcts.so")
 
 EVAL_UNIFORM, EVAL_HASH = 0, 1
+WORKERS_SEQUENTIAL, WORKERS_CONCURRENT = 0, 1
 LEAF_NONE, LEAF_EXPAND, LEAF_TERMINAL = 0, 1, 2
 
 ERR_INVALID_MOVE, ERR_BAD_SIMS, ERR_NOT_DIST, ERR_EPS_RANGE, ERR_BAD_XY = 1, 2, 3, 4, 5
@@ -41,6 +42,10 @@ SYMBOLS = [
     ("az_set_alpha_default", _i, [_vp]),
     ("az_set_threads", _i, [_vp, _i]),
     ("az_get_threads", _i, [_vp]),
+    ("az_set_schedule", _i, [_vp, _i]),
+    ("az_get_schedule", _i, [_vp]),
+    ("az_select_workers", _i, [_vp, _i, _vp, _vp, _vp]),
+    ("az_expand_backup_workers", _i, [_vp, _i, _vp, _vp, _i, _vp]),
     ("az_set_cuda", _i, [_vp, _i]),
     ("az_get_cuda", _i, [_vp]),
     ("az_set_player", _i, [_vp, _i, _i]),
@@ -189,6 +194,8 @@ class Engine:
     def set_alpha_default(self): self._check(self.L.az_set_alpha_default(self.h))
     def set_threads(self, v): self._check(self.L.az_set_threads(self.h, v))
     def get_threads(self): return self.L.az_get_threads(self.h)
+    def set_schedule(self, v): self._check(self.L.az_set_schedule(self.h, int(v)))
+    def get_schedule(self): return self.L.az_get_schedule(self.h)
     def set_cuda(self, v): self._check(self.L.az_set_cuda(self.h, v))
     def get_cuda(self): return self.L.az_get_cuda(self.h)
     def device_bytes(self): return self.L.az_device_bytes(self.h)
@@ -243,6 +250,12 @@ class Engine:
 
     def expand_backup(self, d_value, d_prior, prior_is_log, stream=None):
         self._check(self.L.az_expand_backup(self.h, _ptr(d_value), _ptr(d_prior), int(prior_is_log), stream))
+
+    def select_workers(self, n_workers, d_boards, d_leaf_kind, stream=None):
+        self._check(self.L.az_select_workers(self.h, int(n_workers), _ptr(d_boards), _ptr(d_leaf_kind), stream))
+
+    def expand_backup_workers(self, n_workers, d_value, d_prior, prior_is_log, stream=None):
+        self._check(self.L.az_expand_backup_workers(self.h, int(n_workers), _ptr(d_value), _ptr(d_prior), int(prior_is_log), stream))
 
     def simulate_net(self, n, d_params, layers, stream=None, sync=True):
         """n searches per active tree with the fused network kernel as the predictor,

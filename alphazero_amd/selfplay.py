@@ -48,6 +48,7 @@ class TreeBatch:
         self.dev = torch.device("cuda", device)
         self.boards = torch.zeros((n_trees, 2, shape, shape), dtype=torch.float32, device=self.dev)
         self.kinds = torch.zeros(n_trees, dtype=torch.int32, device=self.dev)
+        self._wboards = self._wkinds = None  # leaf staging of concurrent workers, made on first use
 
     def close(self):
         self.eng.close()
@@ -97,6 +98,21 @@ class TreeBatch:
                 eng.simulate_net(n, self.evaluator.params.data_ptr(), self.evaluator.fused_layers, stream, sync=False)
             except _E.EngineError as e:
                 raise RuntimeError(str(e)) from None
+            return
+        if th_num > 1 and eng.get_schedule() == _E.WORKERS_CONCURRENT:
+            # the workers in lock step (az_set_schedule): th_num leaves per tree in every evaluator call
+            if self._wboards is None or self._wboards.shape[0] != self.n_trees * th_num:
+                self._wboards = torch.zeros((self.n_trees * th_num, 2, self.shape, self.shape), dtype=torch.float32, device=self.dev)
+                self._wkinds = torch.zeros(self.n_trees * th_num, dtype=torch.int32, device=self.dev)
+            with torch.no_grad():
+                eng.begin_simulate(stream)
+                for _ in range(per):
+                    eng.select_workers(th_num, self._wboards.data_ptr(), self._wkinds.data_ptr(), stream)
+                    if getattr(self.evaluator, "takes_leaf_kinds", False):
+                        value, prior = self.evaluator(self._wboards, self._wkinds)
+                    else:
+                        value, prior = self.evaluator(self._wboards)
+                    eng.expand_backup_workers(th_num, value.data_ptr(), prior.data_ptr(), self.evaluator.log_priors, stream)
             return
         with torch.no_grad():
             for _ in range(th_num):

@@ -93,6 +93,21 @@ double az_get_alpha(const az_engine *e);              /* cmcts.cpp:63 */
 int    az_set_alpha_default(az_engine *e);            /* cmcts.cpp:75-81 */
 int    az_set_threads(az_engine *e, int threads);     /* cmcts.cpp:61 */
 int    az_get_threads(const az_engine *e);
+/* How az_simulate_net and the az_*_workers entry points run the `threads` workers of a tree
+ * (cmcts.cpp:98-119; in the reference they are std::threads and their interleaving is not
+ * reproducible):
+ *   AZ_WORKERS_CONCURRENT (default)  in lock step: per step every worker descends to its leaf in
+ *       worker order under virtual loss, the leaves of all workers and trees are evaluated in one
+ *       batch, every worker finishes (set_prior + backup) in worker order.  simulate(n) then
+ *       takes ceil(n / threads) evaluator launches instead of n.
+ *   AZ_WORKERS_SEQUENTIAL            one worker after another, each running its searches alone.
+ * Both are legal executions of the reference's thread fan-out, with its rounding of the
+ * per-worker count and its per-worker noise stream.  az_simulate_fused always runs the
+ * sequential schedule.  (No counterpart in the reference: it has one, unnamed, schedule.) */
+enum { AZ_WORKERS_SEQUENTIAL = 0, AZ_WORKERS_CONCURRENT = 1 };
+#define AZ_MAX_WORKERS 64
+int    az_set_schedule(az_engine *e, int schedule);
+int    az_get_schedule(const az_engine *e);
 int    az_set_cuda(az_engine *e, int cuda);           /* cmcts.cpp:70: always fails, like the reference */
 int    az_get_cuda(const az_engine *e);               /* cmcts.cpp:69 */
 
@@ -144,7 +159,9 @@ int az_get_noise_table(az_engine *e, double *noise, int rows);
 /* Cmcts::simulate (cmcts.cpp:83-125) with the evaluator computed in-kernel:
  * n searches on every active tree, whole call in one launch.  Thread fan-out
  * rounding of cmcts.cpp:98-107 is applied when threads > 1 (workers run one
- * after another, each restarting the noise stream). */
+ * after another, each restarting the noise stream).  A tree in which concurrent
+ * workers have left visit deficits (see az_set_schedule; only az_simulate_net and
+ * az_*_workers do) is refused with AZ_ERR_STATE until it is cleared. */
 int az_simulate_fused(az_engine *e, int n, int eval_kind, float const_prior, float const_value,
                       unsigned long long hash_seed, void *stream);
 
@@ -163,12 +180,24 @@ int az_begin_simulate(az_engine *e, void *stream);
 int az_select(az_engine *e, float *d_boards, int *d_leaf_kind, void *stream);
 int az_expand_backup(az_engine *e, const float *d_value, const float *d_prior, int prior_is_log,
                      void *stream);
+/* The same step for n_workers concurrent workers per tree (threads > 1 with the concurrent
+ * schedule; n_workers <= the engine's threads): all arrays hold n_workers entries per tree,
+ * worker w of tree t at index t * n_workers + w.  az_select_workers runs the workers' descents in
+ * worker order (every visit and virtual loss, node.cpp:115-118, is visible to the next worker;
+ * Node::next_node, node.cpp:126-134, creates the child during the descent, so later workers of the
+ * step may stop at the same unexpanded node); az_expand_backup_workers finishes them in worker
+ * order (set_prior is skipped for a node an earlier worker of the step has expanded,
+ * node.cpp:30-33).  az_begin_simulate restarts every worker's noise stream. */
+int az_select_workers(az_engine *e, int n_workers, float *d_boards, int *d_leaf_kind, void *stream);
+int az_expand_backup_workers(az_engine *e, int n_workers, const float *d_value, const float *d_prior, int prior_is_log,
+                             void *stream);
 
 /* Cmcts::simulate (cmcts.cpp:83-125) with the reference network as the predictor
  * (the torch::jit module of cmcts.cpp:137,217): n searches on every active tree,
  * each search step = az_select, az_net_eval on the step's leaves, az_expand_backup,
  * all queued on `stream` by this one call (the loop of cmcts.cpp:151-154 without a
- * return to the caller per search; thread fan-out as in az_simulate_fused).  An
+ * return to the caller per search; threads > 1: the workers in lock step or one after
+ * another, see az_set_schedule).  An
  * engine of at most one tree per CU runs the whole call as ONE launch (a workgroup
  * per tree selects, evaluates and backs up; same arithmetic, same results).
  * d_params / *_layers: as az_net_eval takes them.  The step's leaf boards, codes,

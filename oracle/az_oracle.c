@@ -331,6 +331,7 @@ struct azo_tree {
     double cpuct;   /* stored as double (cmcts.h:76) */
     double dir_eps;
     int threads;
+    int schedule; /* AZO_SCHEDULE_*: how the workers of threads > 1 interleave */
     int cuda;
     /* counters */
     long long sims, expansions, terminals, select_calls;
@@ -386,6 +387,8 @@ double azo_get_eps(const azo_tree *t) { return t->dir_eps; }
 void azo_set_cpuct(azo_tree *t, float cpuct) { t->cpuct = cpuct; }
 float azo_get_cpuct(const azo_tree *t) { return (float)t->cpuct; }
 void azo_set_threads(azo_tree *t, int threads) { t->threads = threads; }
+void azo_set_schedule(azo_tree *t, int schedule) { t->schedule = schedule; }
+int azo_get_schedule(const azo_tree *t) { return t->schedule; }
 int azo_get_threads(const azo_tree *t) { return t->threads; }
 void azo_set_alpha(azo_tree *t, double alpha)
 {
@@ -543,6 +546,124 @@ static void *worker_main(void *arg)
     return NULL;
 }
 
+/* ------------------------------------------------------------------ */
+/* Lock-step schedule of the thread fan-out (cmcts.cpp:98-119).          */
+/* The reference's workers are std::threads whose interleaving the OS    */
+/* decides; every interleaving in which each node operation is atomic    */
+/* (they run under the node's mutex) is a legal execution.  This is ONE  */
+/* of them, fixed: in step i the workers 0..T-1, in that order, run      */
+/* their i-th search down to its leaf (select with virtual loss,         */
+/* make_move, next_node: cmcts.cpp:189-268), then the leaves are         */
+/* evaluated, then the workers 0..T-1, in that order, finish their       */
+/* search (set_prior, which does nothing when an earlier worker expanded */
+/* the same node, node.cpp:30-33; backup, cmcts.cpp:271-279).            */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    az_state ss;
+    az_node **nodes;
+    int *actions;
+    int depth;
+    az_node *leaf;   /* node to expand, NULL when the search ended on a finished game */
+    float value;     /* value of a finished game */
+    int noise_row;   /* the worker's own generator (cmcts.cpp:132-133) */
+} az_pending;
+
+static int lockstep_descend(azo_tree *t, az_pending *p, long long *cnt, char *err, size_t err_len)
+{
+    az_node *cur = t->root;
+    state_copy(&p->ss, &t->state);
+    p->depth = 0;
+    p->leaf = NULL;
+    p->value = 0.f;
+    for (;;) {
+        if (cur->nodeN == -1) { /* cmcts.cpp:190 */
+            p->leaf = cur;
+            return 0;
+        }
+        int a = node_select(cur, &p->ss, t->cpuct);
+        cnt[3]++;
+        if (a < 0) {
+            snprintf(err, err_len, "No action chosen. Incorrect behaviour");
+            return AZO_ERR_NO_ACTION;
+        }
+        state_make_move(&p->ss, a);
+        p->nodes[p->depth] = cur;
+        p->actions[p->depth] = a;
+        p->depth++;
+        if (p->ss.winner != -1.f) { /* cmcts.cpp:253-267 */
+            p->value = (p->ss.winner == 0.f || p->ss.winner == 1.f) ? 1.f : 0.f;
+            cnt[2]++;
+            return 0;
+        }
+        cur = node_next(cur, a, t->size);
+    }
+}
+
+static int lockstep_finish(azo_tree *t, az_pending *p, const azo_evaluator *ev, const double *noise, int noise_rows,
+                           float *prior, long long *cnt, char *err, size_t err_len)
+{
+    float value = p->value;
+    if (p->leaf) {
+        float v;
+        int is_log = evaluate(t, ev, &p->ss, &v, prior);
+        value = -v; /* cmcts.cpp:228 */
+        const double *row = NULL;
+        if (noise) {
+            /* (only a worker that really expands needs a row; checked like the sequential path) */
+            if (p->leaf->nodeN == -1 && p->noise_row >= noise_rows) {
+                snprintf(err, err_len, "noise table exhausted (%d rows)", noise_rows);
+                return AZO_ERR_NOISE_ROWS;
+            }
+            row = noise + (size_t)p->noise_row * t->size;
+        } else if (t->dir_eps != 0.) {
+            snprintf(err, err_len, "eps != 0 needs a noise table");
+            return AZO_ERR_NOISE_ROWS;
+        }
+        if (node_set_prior(p->leaf, t->size, prior, is_log, row, t->dir_eps)) {
+            if (noise)
+                p->noise_row++;
+            cnt[1]++;
+        }
+    }
+    for (int d = p->depth - 1; d >= 0; d--) {
+        node_backpropagate(p->nodes[d], p->actions[d], value);
+        value = -value;
+    }
+    cnt[0]++;
+    return 0;
+}
+
+static int simulate_lockstep(azo_tree *t, int th_num, int per, const azo_evaluator *ev, const double *noise, int noise_rows)
+{
+    az_pending *ps = (az_pending *)calloc(th_num, sizeof(az_pending));
+    float *prior = (float *)malloc(sizeof(float) * t->size);
+    for (int w = 0; w < th_num; w++) {
+        state_init(&ps[w].ss, t->shape);
+        ps[w].nodes = (az_node **)malloc(sizeof(az_node *) * (t->size + 1));
+        ps[w].actions = (int *)malloc(sizeof(int) * (t->size + 1));
+    }
+    long long cnt[4] = {0, 0, 0, 0};
+    int rc = 0;
+    for (int i = 0; i < per && !rc; i++) {
+        for (int w = 0; w < th_num && !rc; w++)
+            rc = lockstep_descend(t, &ps[w], cnt, g_err, sizeof g_err);
+        for (int w = 0; w < th_num && !rc; w++)
+            rc = lockstep_finish(t, &ps[w], ev, noise, noise_rows, prior, cnt, g_err, sizeof g_err);
+    }
+    t->sims += cnt[0];
+    t->expansions += cnt[1];
+    t->terminals += cnt[2];
+    t->select_calls += cnt[3];
+    for (int w = 0; w < th_num; w++) {
+        state_free(&ps[w].ss);
+        free(ps[w].nodes);
+        free(ps[w].actions);
+    }
+    free(ps);
+    free(prior);
+    return rc;
+}
+
 /* cmcts.cpp:83-125 */
 int azo_simulate(azo_tree *t, int n, const azo_evaluator *ev, const double *noise, int noise_rows)
 {
@@ -560,6 +681,8 @@ int azo_simulate(azo_tree *t, int n, const azo_evaluator *ev, const double *nois
             n = n / th_num;
         else
             n = n / th_num + 1; /* overshoots the request (cmcts.cpp:106-107) */
+        if (t->schedule == AZO_SCHEDULE_LOCKSTEP)
+            return simulate_lockstep(t, th_num, n, ev, noise, noise_rows);
         pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * th_num);
         az_worker *ws = (az_worker *)calloc(th_num, sizeof(az_worker));
         for (int i = 0; i < th_num; i++) {

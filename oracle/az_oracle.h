@@ -83,6 +83,14 @@ void   azo_set_cpuct(azo_tree *t, float cpuct);                /* cmcts.cpp:58  
 float  azo_get_cpuct(const azo_tree *t);                       /* cmcts.cpp:57    */
 void   azo_set_threads(azo_tree *t, int threads);              /* cmcts.cpp:61    */
 int    azo_get_threads(const azo_tree *t);
+/* how the workers of threads > 1 interleave: real threads as in the reference (the default; not
+ * reproducible), or the fixed lock-step interleaving described at simulate_lockstep in az_oracle.c
+ * (per step: every worker descends to its leaf in worker order, the leaves are evaluated, every
+ * worker finishes in worker order) -- one legal execution of cmcts.cpp:98-119, the one the GPU
+ * engine's concurrent schedule is compared with */
+enum { AZO_SCHEDULE_THREADS = 0, AZO_SCHEDULE_LOCKSTEP = 1 };
+void   azo_set_schedule(azo_tree *t, int schedule);
+int    azo_get_schedule(const azo_tree *t);
 void   azo_set_alpha(azo_tree *t, double alpha);               /* cmcts.cpp:64    */
 double azo_get_alpha(const azo_tree *t);                       /* cmcts.cpp:63    */
 void   azo_set_alpha_default(azo_tree *t);                     /* cmcts.cpp:75-81 */

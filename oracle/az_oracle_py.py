@@ -59,6 +59,8 @@ def lib():
         L.azo_get_cpuct.restype = C.c_float
         L.azo_set_threads.argtypes = [C.c_void_p, C.c_int]
         L.azo_set_threads.restype = None
+        L.azo_set_schedule.argtypes = [C.c_void_p, C.c_int]
+        L.azo_set_schedule.restype = None
         L.azo_get_threads.argtypes = [C.c_void_p]
         L.azo_set_alpha.argtypes = [C.c_void_p, C.c_double]
         L.azo_set_alpha.restype = None
@@ -163,6 +165,7 @@ class OracleTree:
     def set_cpuct(self, c): self.L.azo_set_cpuct(self.h, c)
     def get_cpuct(self): return self.L.azo_get_cpuct(self.h)
     def set_threads(self, t): self.L.azo_set_threads(self.h, t)
+    def set_schedule(self, s): self.L.azo_set_schedule(self.h, s)  # 0 = real threads, 1 = lock step (az_oracle.h)
     def set_alpha(self, a): self.L.azo_set_alpha(self.h, a)
     def get_alpha(self): return self.L.azo_get_alpha(self.h)
     def set_alpha_default(self): self.L.azo_set_alpha_default(self.h)

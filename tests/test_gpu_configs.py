@@ -61,6 +61,7 @@ def test_simulate_net_equals_the_three_step_path(S, threads):
         e = E.Engine(B, S, nodes_per_tree=sims * plies + 64, cpuct=4.0)
         e.set_alpha_default()
         e.set_eps(0.25)
+        e.set_schedule(E.WORKERS_SEQUENTIAL)  # this test steps the workers one after another by hand
         e.set_threads(threads)
         e.set_noise_table(np.random.default_rng(4).dirichlet(np.full(size, e.get_alpha()), size=sims + 2))
         e.make_move(np.array([O.opening(size, 7 * g + 1)[0] for g in range(B)], np.int32))

@@ -1,0 +1,248 @@
+"""threads > 1 as concurrent workers in lock step (az_set_schedule, az_select_workers /
+az_expand_backup_workers, az_simulate_net) against the oracle's same-schedule mode
+(azo_set_schedule(LOCKSTEP): one legal interleaving of the reference's std::threads,
+cmcts.cpp:98-119): visit counts, value sums, priors, nodeN and the counters bit-exact, through
+re-rooting, with workers that meet in one unexpanded node, with the per-worker count rounding and
+the per-worker noise stream."""
+import numpy as np
+import pytest
+
+import az_oracle_py as O
+from helpers import ExactTorchEvaluator, oracle_exact_evaluator
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(S, T, eps):
+    t = O.OracleTree(S, cpuct=4.0)
+    t.set_alpha_default()
+    t.set_eps(eps)
+    t.set_threads(T)
+    t.set_schedule(1)
+    return t
+
+
+def _compare(batch, trees, paths=((),)):
+    counts, root_n = batch.eng.get_counts()
+    for g, ot in enumerate(trees):
+        assert root_n[g] == ot.root_n(), g
+        assert np.array_equal(counts[g].astype(np.int64), ot.root_counts()), g
+        for path in paths:
+            got, want = batch.eng.get_node(g, list(path)), ot.node_at(list(path))
+            assert (got is None) == (want is None), (g, path)
+            if got is not None:
+                assert got[0] == want[0], (g, path)                      # nodeN (visit deficit included)
+                assert np.array_equal(got[1].astype(np.int64), want[1]), (g, path)
+                assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3]), (g, path)
+    return counts
+
+
+@pytest.mark.parametrize("S,T,sims", [(9, 2, 31), (9, 4, 50), (9, 8, 3), (15, 4, 100), (15, 8, 40), (15, 2, 64),
+                                      (20, 4, 60), (20, 8, 33), (20, 2, 25)])
+@pytest.mark.parametrize("eps", [0.0, 0.25])
+def test_concurrent_workers_match_the_oracle_lockstep(S, T, sims, eps):
+    from alphazero_amd import selfplay as sp
+
+    G, plies, size = 5, 4, S * S
+    batch = sp.TreeBatch(G, S, ExactTorchEvaluator(), cpuct=4.0, eps=eps, threads=T, nodes_per_tree=(sims + 2 * T) * plies + 64)
+    noise = np.random.default_rng(S + T).dirichlet(np.full(size, batch.eng.get_alpha()), size=sims + 2)
+    if eps:
+        batch.set_noise_table(noise)
+    trees = [_oracle(S, T, eps) for _ in range(G)]
+    first = np.array([O.opening(size, 5 * g + 1)[0] for g in range(G)], np.int32)
+    batch.make_move(first)
+    for ot, a in zip(trees, first):
+        ot.make_move(int(a))
+    oev = oracle_exact_evaluator(S)
+    for ply in range(plies):
+        batch.simulate(sims)
+        for ot in trees:
+            ot.simulate(sims, oev, noise if eps else None)
+        counts = _compare(batch, trees)
+        best = counts.argmax(axis=1)
+        if not counts.any():  # n < threads on a fresh root: every worker only met the unexpanded root
+            raw = batch.eng.get_raw_boards().reshape(G, 2, size).sum(axis=1)
+            best = (raw == 0).argmax(axis=1)
+        for g, ot in enumerate(trees):
+            a = int(best[g])
+            got, want = batch.eng.get_node(g, [a]), ot.node_at([a])
+            assert (got is None) == (want is None)
+            if got is not None:
+                assert got[0] == want[0] and np.array_equal(got[1].astype(np.int64), want[1]) and np.array_equal(got[2], want[2])
+        st = batch.eng.get_stats()
+        want = {k: sum(ot.stats()[k] for ot in trees) for k in st}
+        assert st == want, ply
+        batch.make_move(best.astype(np.int32))
+        for ot, a in zip(trees, best):
+            ot.make_move(int(a))
+    batch.close()
+
+
+class _Sharp:
+    """Nearly all prior mass on the first empty cell: the workers of a step crowd into the same new child."""
+    log_priors = False
+    name = "sharp"
+
+    def __call__(self, boards):
+        import torch
+
+        B, _, S, _ = boards.shape
+        size = S * S
+        occupied = boards.reshape(B, 2, size).sum(1) > 0
+        first_empty = (~occupied).to(torch.int32).argmax(dim=1)
+        p = torch.full((B, size), 1e-4, dtype=torch.float32, device=boards.device)
+        p[torch.arange(B, device=boards.device), first_empty] = 0.9
+        return torch.zeros(B, dtype=torch.float32, device=boards.device), p
+
+
+def _sharp_numpy(board, player):
+    size = board.shape[-1] ** 2
+    p = np.full(size, 1e-4, np.float32)
+    p[np.flatnonzero(board.reshape(2, size).sum(axis=0) == 0)[0]] = 0.9
+    return 0.0, p
+
+
+def test_workers_that_meet_in_an_unexpanded_node_leave_a_visit_deficit():
+    from alphazero_amd import engine as E
+    from alphazero_amd import selfplay as sp
+
+    S, T, sims = 9, 4, 24
+    batch = sp.TreeBatch(3, S, _Sharp(), cpuct=4.0, eps=0.0, threads=T, nodes_per_tree=512)
+    trees = [_oracle(S, T, 0.0) for _ in range(3)]
+    oev = O.callback_evaluator(_sharp_numpy, S, log_priors=False)
+    for ply in range(3):
+        batch.simulate(sims)
+        for ot in trees:
+            ot.simulate(sims, oev)
+        counts = _compare(batch, trees)
+        a = int(counts[0].argmax())
+        child, want = batch.eng.get_node(0, [a]), trees[0].node_at([a])
+        assert child[0] == want[0] and np.array_equal(child[1].astype(np.int64), want[1]) and np.array_equal(child[2], want[2])
+        if ply == 0:
+            assert child[0] < counts[0][a] - 1  # the deficit: fewer selects from the child than visits of the action minus one
+        # two levels down as well
+        b = int(child[1].argmax())
+        g2, w2 = batch.eng.get_node(0, [a, b]), trees[0].node_at([a, b])
+        assert (g2 is None) == (w2 is None)
+        if g2 is not None:
+            assert g2[0] == w2[0] and np.array_equal(g2[1].astype(np.int64), w2[1]) and np.array_equal(g2[2], w2[2])
+        assert batch.eng.get_stats() == {k: sum(ot.stats()[k] for ot in trees) for k in ("sims", "expansions", "terminals", "select_calls")}
+        move = counts.argmax(axis=1).astype(np.int32)
+        batch.make_move(move)  # re-rooting onto a node that carries a deficit
+        for ot, m in zip(trees, move):
+            ot.make_move(int(m))
+    # the single-worker kernels walk such a tree correctly (sequential schedule) ...
+    batch.eng.set_schedule(E.WORKERS_SEQUENTIAL)
+    batch.eng.set_threads(0)
+    for ot in trees:
+        ot.set_threads(0)
+    batch.simulate(10)
+    for ot in trees:
+        ot.simulate(10, oev)
+    _compare(batch, trees)
+    # ... and the in-kernel-evaluator search, which cannot, refuses it
+    with pytest.raises(E.EngineError) as ei:
+        batch.eng.simulate_fused(5, E.EVAL_HASH, hash_seed=1)
+    assert ei.value.code == E.ERR_STATE
+    batch.eng.clear()
+    batch.eng.simulate_fused(5, E.EVAL_HASH, hash_seed=1)
+    batch.close()
+
+
+@pytest.mark.parametrize("B,S,T,sims", [(6, 15, 4, 50), (300, 15, 4, 22), (6, 20, 8, 5), (40, 9, 3, 31)])
+def test_simulate_net_runs_the_workers_in_lock_step(B, S, T, sims):
+    """az_simulate_net with threads > 1 queues exactly the launches of az_select_workers / az_net_eval /
+    az_expand_backup_workers (per-worker count rounded up as cmcts.cpp:98-107; n < threads: n workers of one
+    search): every statistic bit-identical, and ceil(n / T) evaluator steps instead of n."""
+    import torch
+    from alphazero_amd import engine as E
+    from test_gpu_configs import _fused
+
+    size, plies = S * S, 2
+    _, ev = _fused(S, seed=3)
+    engs = []
+    for _ in range(2):
+        e = E.Engine(B, S, nodes_per_tree=(sims + 2 * T) * plies + 64, cpuct=4.0)
+        e.set_alpha_default()
+        e.set_eps(0.25)
+        e.set_threads(T)
+        assert e.get_schedule() == E.WORKERS_CONCURRENT
+        e.set_noise_table(np.random.default_rng(4).dirichlet(np.full(size, e.get_alpha()), size=sims + 2))
+        e.make_move(np.array([O.opening(size, 7 * g + 1)[0] for g in range(B)], np.int32))
+        engs.append(e)
+    a, b = engs
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    nw = min(T, sims)
+    per = 1 if sims < T else (sims // T if sims % T == 0 else sims // T + 1)
+    boards = torch.zeros((B * nw, 2, S, S), dtype=torch.float32, device=dev)
+    kinds = torch.zeros(B * nw, dtype=torch.int32, device=dev)
+    for ply in range(plies):
+        a.simulate_net(sims, ev.params.data_ptr(), ev.fused_layers, stream)
+        b.begin_simulate(stream)
+        for _ in range(per):
+            b.select_workers(nw, boards.data_ptr(), kinds.data_ptr(), stream)
+            value, logp = ev(boards, kinds)
+            b.expand_backup_workers(nw, value.data_ptr(), logp.data_ptr(), True, stream)
+        b.sync_check(stream)
+        ca, ra = a.get_counts()
+        cb, rb = b.get_counts()
+        assert np.array_equal(ra, rb) and np.array_equal(ca, cb), ply
+        assert ra.max() > 0 or sims < T  # n < threads: n workers of one search, which all meet the unexpanded root
+        for t in range(0, B, max(1, B // 6)):
+            na, nb = a.get_node(t, []), b.get_node(t, [])
+            assert np.array_equal(na[2], nb[2]) and np.array_equal(na[3], nb[3]), (ply, t)
+        assert a.get_stats() == b.get_stats()
+        assert a.get_stats()["sims"] == B * nw * per * (ply + 1)
+        act = ca.argmax(axis=1).astype(np.int32)
+        if not ca.any():
+            act = (a.get_raw_boards().reshape(B, 2, size).sum(axis=1) == 0).argmax(axis=1).astype(np.int32)
+        a.make_move(act)
+        b.make_move(act)
+    a.close()
+    b.close()
+
+
+def test_simulate_net_lock_step_matches_the_oracle():
+    """The engine-driven network search with four concurrent workers against the oracle in lock-step mode,
+    whose predictor returns what the fused kernel computes for the position it is asked about."""
+    import torch
+    from alphazero_amd import engine as E
+    from test_gpu_configs import _fused
+
+    S, B, T, sims, plies = 15, 3, 4, 60, 3
+    size = S * S
+    _, ev = _fused(S, seed=5)
+    dev = torch.device("cuda", 0)
+
+    def predictor(raw, player):
+        boards = torch.from_numpy(raw.astype(np.float32)).reshape(1, 2, S, S).to(dev)
+        value, logp = ev(boards)
+        return float(value.cpu()[0]), logp.cpu().numpy()[0]
+
+    oev = O.callback_evaluator(predictor, S, log_priors=True)
+    eng = E.Engine(B, S, nodes_per_tree=(sims + 8) * plies + 64, cpuct=4.0)
+    eng.set_alpha_default()
+    eng.set_eps(0.25)
+    eng.set_threads(T)
+    noise = np.random.default_rng(6).dirichlet(np.full(size, eng.get_alpha()), size=sims + 2)
+    eng.set_noise_table(noise)
+    trees = [_oracle(S, T, 0.25) for _ in range(B)]
+    act = np.array([O.opening(size, 11 * g + 3)[0] for g in range(B)], np.int32)
+    eng.make_move(act)
+    for t, a in zip(trees, act):
+        t.make_move(int(a))
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for ply in range(plies):
+        eng.simulate_net(sims, ev.params.data_ptr(), ev.fused_layers, stream)
+        counts, root_n = eng.get_counts()
+        for t, ot in enumerate(trees):
+            ot.simulate(sims, oev, noise)
+            assert root_n[t] == ot.root_n()
+            assert np.array_equal(counts[t].astype(np.int64), ot.root_counts()), (ply, t)
+            np.testing.assert_allclose(eng.get_node(t, [])[3], ot.root_p(), rtol=1e-6, atol=0)  # device expf vs host expf
+        act = counts.argmax(axis=1).astype(np.int32)
+        eng.make_move(act)
+        for t, a in zip(trees, act):
+            t.make_move(int(a))
+    eng.close()

@@ -162,3 +162,50 @@ def test_select_arrays_branches_and_ties():
     assert O.select_arrays(n, w, p2, node_n, board, 4.0) == 7
     board[:] = 1
     assert O.select_arrays(n, w, p, node_n, board, 4.0) == -1  # no legal action
+
+
+def test_lockstep_schedule_of_the_thread_fanout_is_deterministic_and_conserves_visits():
+    """threads > 1 with the lock-step interleaving (az_oracle.h): in the first step of a call on a fresh
+    root all T workers meet the unexpanded root, one expands it and none counts a visit
+    (cmcts.cpp:190-243, node.cpp:30-33), so root nodeN = T * (per - 1); the visit counts add up;
+    two runs agree bit for bit; workers that meet in one unexpanded child both count a visit of the
+    action while the child itself has been selected from by neither."""
+    S, size = 9, 81
+    for T, n in ((4, 50), (2, 7), (8, 3), (3, 30)):
+        per = 1 if n < T else (n // T if n % T == 0 else n // T + 1)
+        th = min(T, n)
+        runs = []
+        for _ in range(2):
+            t = O.OracleTree(S, cpuct=4.0)
+            t.set_eps(0.25)
+            t.set_alpha_default()
+            t.set_threads(T)
+            t.set_schedule(1)
+            noise = np.random.default_rng(5).dirichlet(np.full(size, t.get_alpha()), size=per + 2)
+            t.make_move(40)
+            t.simulate(n, O.hash_evaluator(3), noise)
+            assert t.root_n() == th * (per - 1)
+            assert t.root_counts().sum() == t.root_n()
+            st = t.stats()
+            assert st["sims"] == th * per and st["expansions"] + st["terminals"] <= st["sims"]
+            runs.append((t.root_counts().copy(), t.root_w().copy(), t.root_p().copy(), st))
+        assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+        assert np.array_equal(runs[0][2], runs[1][2]) and runs[0][3] == runs[1][3]
+    # a sharp prior drives several workers of a step into the same new child
+    t = O.OracleTree(S, cpuct=4.0)
+    t.set_eps(0.0)
+    t.set_threads(4)
+    t.set_schedule(1)
+
+    def sharp(board, player):
+        p = np.full(size, 1e-4, np.float32)
+        empty = np.flatnonzero(board.reshape(2, size).sum(axis=0) == 0)
+        p[empty[0]] = 0.9
+        return 0.0, p
+
+    t.simulate(12, O.callback_evaluator(sharp, S, log_priors=False))
+    counts = t.root_counts()
+    a = int(counts.argmax())
+    assert counts[a] >= 2
+    child = t.node_at([a])
+    assert child is not None and child[0] < counts[a] - 1  # fewer selects from the child than visits of the action minus one

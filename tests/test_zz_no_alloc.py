@@ -50,10 +50,13 @@ def test_noalloc_entry_point_equals_az_simulate_net():
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     # first call: 600 trees of 15x15; second: 300 trees of 9x9 over the first call's leftovers.  Both batches hold
     # more trees than the GPU has CUs: a batch of at most one tree per CU would run as one launch that stages in LDS.
-    for B, S, sims, seed in ((600, 15, 40, 1), (300, 9, 30, 2)):
+    # third call: four concurrent workers per tree (the staging then holds four leaves per tree)
+    for B, S, sims, seed, threads in ((600, 15, 40, 1, 0), (300, 9, 30, 2, 0), (280, 9, 30, 3, 4)):
         assert B > cus
         ev = evs[S]
         fixed, ref = _pair(E, B, S, sims, seed)
+        for e in (fixed, ref):
+            e.set_threads(threads)  # (allocates the workers' state: the search call itself allocates nothing)
         for ply in range(2):
             torch.cuda.synchronize()
             held, free_before = fixed.device_bytes(), torch.cuda.mem_get_info(0)[0]

@@ -1293,35 +1293,103 @@ __global__ __launch_bounds__(64) AZ_STEP_OCC void k_backup_select(AzParams P, co
 // arrive at a node that exists but is not expanded: such a node is marked in AzParams::aux (see az_common.h); the
 // workers that meet there all count a visit of the parent's action, none of them selects from the child, and the
 // surplus is kept as the child's visit deficit once it is expanded.
-__device__ __forceinline__ void wselect_body(const AzParams &P, int tree, int w, int nw, int lane, const WState &root_state,
-                                             float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask, unsigned *d_clear_mask)
+// The tree header and the workers' records live in registers for the duration of a worker kernel: lane i holds
+// 32-bit word i of the header (one global round trip instead of one per field and worker; with one tree per GPU a
+// step's duration is the sum of its dependent round trips), the fields that change are carried in scalars and
+// written back once at the end.
+struct WHdr {
+    int root, root_n, free_top, n_order, err, flags, active;
+    unsigned n_sims, n_exp, n_term;
+    unsigned long long n_sel;
+    int words; // lane i: word i of the AzTree as loaded
+};
+static_assert(sizeof(AzTree) % 4 == 0 && sizeof(AzTree) <= 256, "the header fits one word per lane");
+static_assert(sizeof(AzWorker) == 32, "eight words per worker: eight workers per 64-lane chunk");
+#define AZ_HDR_WORD(words, field) __builtin_amdgcn_readlane(words, (int)(offsetof(AzTree, field) / 4))
+__device__ __forceinline__ void whdr_load(const AzTree *T, int lane, WHdr &h)
+{
+    h.words = lane < (int)(sizeof(AzTree) / 4) ? reinterpret_cast<const int *>(T)[lane] : 0;
+    h.root = AZ_HDR_WORD(h.words, root);
+    h.root_n = AZ_HDR_WORD(h.words, root_n);
+    h.free_top = AZ_HDR_WORD(h.words, free_top);
+    h.n_order = AZ_HDR_WORD(h.words, n_order);
+    h.err = AZ_HDR_WORD(h.words, err);
+    h.flags = AZ_HDR_WORD(h.words, flags);
+    h.active = AZ_HDR_WORD(h.words, active);
+    h.n_sims = h.n_exp = h.n_term = 0u;
+    h.n_sel = 0ull;
+}
+__device__ __forceinline__ void whdr_store(AzTree *T, int lane, const WHdr &h)
+{
+    if (lane != 0) return;
+    T->root = h.root;
+    T->root_n = h.root_n;
+    T->free_top = h.free_top;
+    T->n_order = h.n_order;
+    T->err = h.err;
+    T->flags = h.flags;
+    const int s0 = (int)(offsetof(AzTree, stats) / 4);
+    const unsigned long long add[4] = {h.n_sims, h.n_exp, h.n_term, h.n_sel};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane(h.words, s0 + 2 * k), hi = (unsigned)__builtin_amdgcn_readlane(h.words, s0 + 2 * k + 1);
+        T->stats[k] = (((unsigned long long)hi << 32) | lo) + add[k];
+    }
+}
+// the board and whose move it is, from the header words and the bit rows
+template <int E> __device__ __forceinline__ void load_state_hdr(const AzParams &P, int tree, int lane, int words, WState &s)
+{
+    s.rb = P.rows[tree * 64 + lane];
+    s.player = AZ_HDR_WORD(words, player);
+    s.move_cnt = AZ_HDR_WORD(words, move_cnt);
+    s.winner = __int_as_float(AZ_HDR_WORD(words, winner));
+    s.occ = 0u;
+#pragma unroll
+    for (int k = 0; k < E; k++) {
+        const int a = lane * E + k;
+        const int r = a < SIZE ? a / S : 0, c = a < SIZE ? a % S : 0;
+        const unsigned both = (unsigned)__shfl((int)s.rb, r) | (unsigned)__shfl((int)s.rb, 32 + r);
+        if (a < SIZE && ((both >> c) & 1u)) s.occ |= 1u << k;
+    }
+}
+// fields of a worker's record inside a chunk of eight records held one word per lane
+enum { WF_KIND = 0, WF_PATH_LEN = 1, WF_VALUE = 2, WF_NOISE_ROW = 3, WF_LEAF_SLOT = 4 };
+__device__ __forceinline__ int wget(int wr, int wi, int field) { return __builtin_amdgcn_readlane(wr, wi * 8 + field); }
+__device__ __forceinline__ void wput(int &wr, int lane, int wi, int field, int v) { wr = lane == wi * 8 + field ? v : wr; }
+
+// worker (chunk position wi, index w) descends to its leaf
+__device__ __forceinline__ void wselect_body(const AzParams &P, int tree, int w, int wi, int nw, int lane, const WState &root_state,
+                                             WHdr &h, int &wr, float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask,
+                                             unsigned *d_clear_mask)
 {
     constexpr int E = EPL;
-    AzTree *T = &P.trees[tree];
-    AzWorker *W = &P.workers[(size_t)tree * P.max_workers + w];
     const int out = tree * nw + w;
     if (d_clear_mask != nullptr && lane == 0 && (out & 31) == 0) d_clear_mask[(out >> 5) * AZ_MASK_STRIDE] = 0u;
-    if (uni(T->active) == 0 || uni(T->err) != 0) { // (an error raised by an earlier worker of this step stops the others too)
-        if (lane == 0) { W->leaf_kind = AZ_LEAF_NONE; d_leaf_kind[out] = AZ_LEAF_NONE; }
+    if (h.active == 0 || h.err != 0) { // (an error raised by an earlier worker of this step stops the others too)
+        wput(wr, lane, wi, WF_KIND, AZ_LEAF_NONE);
+        if (lane == 0) d_leaf_kind[out] = AZ_LEAF_NONE;
         return;
     }
     const size_t tbase = (size_t)tree * P.cap;
     int *pn = P.wpath_node + ((size_t)tree * P.max_workers + w) * P.path_cap;
     int *pa = P.wpath_act + ((size_t)tree * P.max_workers + w) * P.path_cap;
     WState s = root_state;
-    const int root = uni(T->root);
+    const int root = h.root;
     int cur = root;
-    int nn = root >= 0 ? uni(T->root_n) : 0;
+    int nn = root >= 0 ? h.root_n : 0;
     int depth = 0, kind = AZ_LEAF_EXPAND, err = 0, phase = 0, leaf_slot = -1;
     float leaf_value = 0.f;
-    unsigned long long n_sel = 0;
+    NodeRegs<E> nd;
+    if (cur >= 0) load_node<E>(P, tree, cur, lane, false, nd); // a root is always materialised
     while (cur >= 0) {
-        const bool fresh = nn == 0 && cur != root; // a root is always materialised
-        NodeRegs<E> nd;
-        load_node<E>(P, tree, cur, lane, fresh, nd);
+        const bool fresh = nn == 0 && cur != root;
+        if (fresh) { // (the record was requested whole before its nodeN was known: only its priors exist yet)
+#pragma unroll
+            for (int k = 0; k < E; k++) { nd.n[k] = 0; nd.link[k] = 0; nd.w[k] = 0.; }
+        }
         const Pick pk = select_pick<1, E>(nd, fresh, sqrt_node_n(nn, nullptr), s.occ, P.cpuct, lane, nullptr, phase);
         if (pk.a < 0) { err = AZ_ERR_NO_ACTION; break; }
-        n_sel++;
+        h.n_sel++;
         char *rec = rec_ptr(P, tree, cur);
         if (fresh) {
 #pragma unroll
@@ -1332,36 +1400,40 @@ __device__ __forceinline__ void wselect_body(const AzParams &P, int tree, int w,
             reinterpret_cast<int *>(rec + OFF_N)[pk.a] = pk.n + 1;
             reinterpret_cast<double *>(rec + OFF_W)[pk.a] = pk.w - 1.;
         }
+        if (cur == root) h.root_n = nn + 1;
         if (lane == 0) {
-            if (cur == root) T->root_n = nn + 1;
             pn[depth] = cur;
             pa[depth] = pk.a;
         }
         depth++;
+        // the child's record and its mark are requested together, before the rules code: one round trip per level
+        const int child = pk.link - 1;
+        int ax = 0;
+        if (child >= 0) {
+            ax = P.aux[tbase + child];
+            load_node<E>(P, tree, child, lane, false, nd);
+        }
         state_move<E>(s, pk.a, lane);
         if (s.winner != -1.f) {
             kind = AZ_LEAF_TERMINAL;
             leaf_value = (s.winner == 0.f || s.winner == 1.f) ? 1.f : 0.f;
             break;
         }
-        if (pk.link == 0) { // Node::next_node creates the child now (node.cpp:126-134); this worker will expand it
-            const int free_top = uni(T->free_top);
-            if (free_top == 0) { err = AZ_ERR_POOL_FULL; break; }
-            const int n_order = uni(T->n_order);
-            const int slot = uni(P.free_stack[tbase + free_top - 1]);
+        if (child < 0) { // Node::next_node creates the child now (node.cpp:126-134); this worker will expand it
+            if (h.free_top == 0) { err = AZ_ERR_POOL_FULL; break; }
+            const int slot = uni(P.free_stack[tbase + h.free_top - 1]);
             if (lane == owner_of<E>(pk.a)) reinterpret_cast<int *>(rec + OFF_LINK)[pk.a] = slot + 1;
             if (lane == 0) {
                 P.parent[tbase + slot] = cur;
-                P.order[tbase + n_order] = slot;
+                P.order[tbase + h.n_order] = slot;
                 P.aux[tbase + slot] = -1;
-                T->free_top = free_top - 1;
-                T->n_order = n_order + 1;
             }
+            h.free_top--;
+            h.n_order++;
             leaf_slot = slot;
             break;
         }
-        const int child = pk.link - 1;
-        const int ax = uni(P.aux[tbase + child]);
+        ax = uni(ax); // (written by lane 0, read back through lane 0)
         if (ax < 0) { // created by an earlier worker of this step and not expanded yet: the leaf of this worker too
             if (lane == 0) P.aux[tbase + child] = ax - 1;
             leaf_slot = child;
@@ -1370,110 +1442,169 @@ __device__ __forceinline__ void wselect_body(const AzParams &P, int tree, int w,
         cur = child;
         nn = pk.n - 1 - ax;
     }
-    if (err) kind = AZ_LEAF_NONE;
+    if (err) { kind = AZ_LEAF_NONE; h.err = err; }
     if (kind == AZ_LEAF_EXPAND) write_board(s, d_boards + (size_t)out * 2 * SIZE, lane);
+    wput(wr, lane, wi, WF_KIND, kind);
+    wput(wr, lane, wi, WF_PATH_LEN, depth);
+    wput(wr, lane, wi, WF_VALUE, __float_as_int(leaf_value));
+    wput(wr, lane, wi, WF_LEAF_SLOT, leaf_slot);
     if (lane == 0) {
-        W->leaf_kind = kind;
-        W->path_len = depth;
-        W->leaf_value = leaf_value;
-        W->leaf_slot = leaf_slot;
-        T->stats[3] += n_sel;
-        if (err) T->err = err;
         d_leaf_kind[out] = kind;
         if (d_expand_mask != nullptr && kind == AZ_LEAF_EXPAND) atomicOr(&d_expand_mask[(out >> 5) * AZ_MASK_STRIDE], 1u << (out & 31));
     }
 }
 
-__device__ __forceinline__ void wbackup_body(const AzParams &P, int tree, int w, int nw, int lane, const float *d_value,
-                                             const float *d_prior, int prior_is_log)
+// worker (chunk position wi, index w) finishes its search: set_prior + backup
+__device__ __forceinline__ void wbackup_body(const AzParams &P, int tree, int w, int wi, int nw, int lane, WHdr &h, int &wr,
+                                             const float *d_value, const float *d_prior, int prior_is_log)
 {
     constexpr int E = EPL;
-    AzTree *T = &P.trees[tree];
-    AzWorker *W = &P.workers[(size_t)tree * P.max_workers + w];
-    const int kind = uni(W->leaf_kind);
+    const int kind = wget(wr, wi, WF_KIND);
     if (kind == AZ_LEAF_NONE) return;
-    if (uni(T->err) != 0) { // an earlier worker of this step failed: the tree is left as it is (no backup either)
-        if (lane == 0) W->leaf_kind = AZ_LEAF_NONE;
-        return;
-    }
+    wput(wr, lane, wi, WF_KIND, AZ_LEAF_NONE);
+    if (h.err != 0) return; // an earlier worker of this step failed: the tree is left as it is (no backup either)
     const int out = tree * nw + w;
     const size_t tbase = (size_t)tree * P.cap;
     const int *pn = P.wpath_node + ((size_t)tree * P.max_workers + w) * P.path_cap;
     const int *pa = P.wpath_act + ((size_t)tree * P.max_workers + w) * P.path_cap;
-    const int depth = uni(W->path_len);
+    const int depth = wget(wr, wi, WF_PATH_LEN);
+    // the path, one level per lane (levels past the 64th are read one by one below)
+    const int pnv = lane < depth ? pn[lane] : 0, pav = lane < depth ? pa[lane] : 0;
+    // The W words of the first PRE levels are requested now, together with everything else this worker reads, so
+    // that the whole backup costs two memory round trips (a path visits a word once, and the expansion below
+    // touches none of them).  Each word is read and written by the lane that owns its action.
+    constexpr int PRE = 8;
+    double oldw[PRE];
+#pragma unroll
+    for (int d = 0; d < PRE; d++) {
+        oldw[d] = 0.;
+        if (d < depth) {
+            const int node = __builtin_amdgcn_readlane(pnv, d), act = __builtin_amdgcn_readlane(pav, d);
+            if (lane == owner_of<E>(act)) oldw[d] = *(reinterpret_cast<const double *>(rec_ptr(P, tree, node) + OFF_W) + act);
+        }
+    }
     float value;
     if (kind == AZ_LEAF_EXPAND) {
-        const int leaf_slot = uni(W->leaf_slot);
-        int slot = leaf_slot, ax = 0, err = 0;
-        bool expand, is_root = leaf_slot < 0;
-        int free_top = 0, n_order = 0;
+        const int leaf_slot = wget(wr, wi, WF_LEAF_SLOT);
+        const bool is_root = leaf_slot < 0;
+        const int noise_row = wget(wr, wi, WF_NOISE_ROW);
+        // requested before it is known whether this worker expands: the node's mark, the value, the priors, the noise
+        int ax = is_root ? 0 : P.aux[tbase + leaf_slot];
+        const float v_in = d_value[out];
+        float pr[E];
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            const int a = lane * E + k;
+            pr[k] = a < SIZE ? d_prior[(size_t)out * SIZE + a] : 0.f;
+        }
+        double nz[E];
+#pragma unroll
+        for (int k = 0; k < E; k++) nz[k] = 0.;
+        if (P.noise != nullptr && noise_row < P.noise_rows)
+            ld_f64<E>(reinterpret_cast<const char *>(P.noise), (unsigned)noise_row * (unsigned)(SP * 8), lane, nz);
+        ax = uni(ax);
+        int slot = leaf_slot, err = 0;
+        bool expand;
         if (is_root) {
-            expand = uni(T->root) < 0; // else an earlier worker of this step has expanded the root
+            expand = h.root < 0; // else an earlier worker of this step has expanded the root
             if (expand) {
-                free_top = uni(T->free_top);
-                n_order = uni(T->n_order);
-                if (free_top == 0) err = AZ_ERR_POOL_FULL;
-                else slot = uni(P.free_stack[tbase + free_top - 1]);
+                if (h.free_top == 0) err = AZ_ERR_POOL_FULL;
+                else slot = uni(P.free_stack[tbase + h.free_top - 1]);
             }
         } else {
-            ax = uni(P.aux[tbase + leaf_slot]);
             expand = ax < 0; // else expanded by the worker that created it (node.cpp:30-33: nothing to do)
         }
-        const int noise_row = uni(W->noise_row);
         if (expand && !err && P.noise != nullptr && noise_row >= P.noise_rows) err = AZ_ERR_NOISE_ROWS;
-        if (err) {
-            if (lane == 0) { T->err = err; W->leaf_kind = AZ_LEAF_NONE; }
-            return;
-        }
+        if (err) { h.err = err; return; }
         if (expand) {
-            float pr[E];
+            // Node::set_prior (node.cpp:38-45), the arithmetic of mix_prior on the rows loaded above
+            NodeRegs<E> nd;
+            const double prior_eps = 1. - P.eps;
 #pragma unroll
             for (int k = 0; k < E; k++) {
-                const int a = lane * E + k;
-                pr[k] = a < SIZE ? d_prior[(size_t)out * SIZE + a] : 0.f;
+                const double p = prior_is_log ? (double)expf(pr[k]) : (double)pr[k];
+                nd.p[k] = (lane * E + k < SIZE) ? prior_eps * p + P.eps * nz[k] : 0.;
             }
-            NodeRegs<E> nd;
-            mix_prior<E>(P, pr, prior_is_log != 0, noise_row, lane, nd.p);
             st_f64<E>(rec_ptr(P, tree, slot), OFF_P, lane, nd.p);
             if (is_root) { // the root is always materialised
 #pragma unroll
                 for (int k = 0; k < E; k++) { nd.n[k] = 0; nd.link[k] = 0; nd.w[k] = 0.; }
                 store_stats<E>(P, tree, slot, lane, nd);
-            }
-            if (lane == 0) {
-                if (is_root) {
-                    T->root = slot;
-                    T->root_n = 0;
+                if (lane == 0) {
                     P.parent[tbase + slot] = -1;
-                    P.order[tbase + n_order] = slot;
+                    P.order[tbase + h.n_order] = slot;
                     P.aux[tbase + slot] = 0;
-                    T->free_top = free_top - 1;
-                    T->n_order = n_order + 1;
-                } else {
-                    const int extra = -ax - 1; // workers that arrived after the one that created the node
-                    P.aux[tbase + slot] = extra;
-                    if (extra > 0) T->flags = T->flags | AZ_TREE_DEFICIT;
                 }
-                if (P.noise != nullptr) W->noise_row = noise_row + 1;
-                T->stats[1] += 1;
+                h.root = slot;
+                h.root_n = 0;
+                h.free_top--;
+                h.n_order++;
+            } else {
+                const int extra = -ax - 1; // workers that arrived after the one that created the node
+                if (lane == 0) P.aux[tbase + slot] = extra;
+                if (extra > 0) h.flags |= AZ_TREE_DEFICIT;
+            }
+            if (P.noise != nullptr) wput(wr, lane, wi, WF_NOISE_ROW, noise_row + 1);
+            h.n_exp++;
+        }
+        value = -unif(v_in); // cmcts.cpp:228
+    } else {
+        value = __int_as_float(wget(wr, wi, WF_VALUE));
+        h.n_term++;
+    }
+    // backup (node.cpp:75-83): the owner of each level's action updates its W
+#pragma unroll
+    for (int d = 0; d < PRE; d++) {
+        if (d < depth) {
+            const int node = __builtin_amdgcn_readlane(pnv, d), act = __builtin_amdgcn_readlane(pav, d);
+            if (lane == owner_of<E>(act)) {
+                const float vd = ((depth - 1 - d) & 1) ? -value : value;
+                *(reinterpret_cast<double *>(rec_ptr(P, tree, node) + OFF_W) + act) = oldw[d] + ((double)vd + 1.);
             }
         }
-        value = -d_value[out]; // cmcts.cpp:228
-    } else {
-        value = unif(W->leaf_value);
-        if (lane == 0) T->stats[2] += 1;
     }
-    for (int d = 0; d < depth; d++) {
-        const int node = uni(pn[d]), act = uni(pa[d]);
+    for (int d = PRE; d < depth; d++) {
+        const int node = d < 64 ? __builtin_amdgcn_readlane(pnv, d) : uni(pn[d]);
+        const int act = d < 64 ? __builtin_amdgcn_readlane(pav, d) : uni(pa[d]);
         if (lane == owner_of<E>(act)) {
             const float vd = ((depth - 1 - d) & 1) ? -value : value;
             double *wp = reinterpret_cast<double *>(rec_ptr(P, tree, node) + OFF_W) + act;
-            *wp += (double)vd + 1.; // node.cpp:80
+            *wp += (double)vd + 1.;
         }
     }
-    if (lane == 0) {
-        W->leaf_kind = AZ_LEAF_NONE;
-        T->stats[0] += 1;
+    h.n_sims++;
+}
+
+// the workers' records of chunk c (eight records, one word per lane)
+__device__ __forceinline__ int wchunk_load(const AzParams &P, int tree, int c, int nw, int lane)
+{
+    const int *base = reinterpret_cast<const int *>(P.workers + (size_t)tree * P.max_workers + c);
+    return lane < 8 * min(8, nw - c) ? base[lane] : 0;
+}
+__device__ __forceinline__ void wchunk_store(const AzParams &P, int tree, int c, int nw, int lane, int wr)
+{
+    int *base = reinterpret_cast<int *>(P.workers + (size_t)tree * P.max_workers + c);
+    if (lane < 8 * min(8, nw - c)) base[lane] = wr;
+}
+__device__ __forceinline__ void workers_select_phase(const AzParams &P, int tree, int nw, int lane, WHdr &h, float *d_boards,
+                                                     int *d_leaf_kind, unsigned *d_expand_mask, unsigned *d_clear_mask)
+{
+    WState rs;
+    load_state_hdr<EPL>(P, tree, lane, h.words, rs);
+    for (int c = 0; c < nw; c += 8) {
+        int wr = wchunk_load(P, tree, c, nw, lane);
+        for (int wi = 0; wi < min(8, nw - c); wi++)
+            wselect_body(P, tree, c + wi, wi, nw, lane, rs, h, wr, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
+        wchunk_store(P, tree, c, nw, lane, wr);
+    }
+}
+__device__ __forceinline__ void workers_backup_phase(const AzParams &P, int tree, int nw, int lane, WHdr &h, const float *d_value,
+                                                     const float *d_prior, int prior_is_log)
+{
+    for (int c = 0; c < nw; c += 8) {
+        int wr = wchunk_load(P, tree, c, nw, lane);
+        for (int wi = 0; wi < min(8, nw - c); wi++) wbackup_body(P, tree, c + wi, wi, nw, lane, h, wr, d_value, d_prior, prior_is_log);
+        wchunk_store(P, tree, c, nw, lane, wr);
     }
 }
 
@@ -1481,24 +1612,29 @@ __global__ __launch_bounds__(64) void k_workers_select(AzParams P, int nw, float
                                                        unsigned *d_clear_mask)
 {
     const int tree = blockIdx.x, lane = threadIdx.x;
-    WState rs;
-    load_state<EPL>(P, tree, lane, rs);
-    for (int w = 0; w < nw; w++) wselect_body(P, tree, w, nw, lane, rs, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
+    WHdr h;
+    whdr_load(&P.trees[tree], lane, h);
+    workers_select_phase(P, tree, nw, lane, h, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
+    whdr_store(&P.trees[tree], lane, h);
 }
 __global__ __launch_bounds__(64) void k_workers_backup(AzParams P, int nw, const float *d_value, const float *d_prior, int prior_is_log)
 {
     const int tree = blockIdx.x, lane = threadIdx.x;
-    for (int w = 0; w < nw; w++) wbackup_body(P, tree, w, nw, lane, d_value, d_prior, prior_is_log);
+    WHdr h;
+    whdr_load(&P.trees[tree], lane, h);
+    workers_backup_phase(P, tree, nw, lane, h, d_value, d_prior, prior_is_log);
+    whdr_store(&P.trees[tree], lane, h);
 }
 __global__ __launch_bounds__(64) void k_workers_backup_select(AzParams P, int nw, const float *d_value, const float *d_prior,
                                                               int prior_is_log, float *d_boards, int *d_leaf_kind,
                                                               unsigned *d_expand_mask, unsigned *d_clear_mask)
 {
     const int tree = blockIdx.x, lane = threadIdx.x;
-    for (int w = 0; w < nw; w++) wbackup_body(P, tree, w, nw, lane, d_value, d_prior, prior_is_log);
-    WState rs;
-    load_state<EPL>(P, tree, lane, rs);
-    for (int w = 0; w < nw; w++) wselect_body(P, tree, w, nw, lane, rs, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
+    WHdr h;
+    whdr_load(&P.trees[tree], lane, h);
+    workers_backup_phase(P, tree, nw, lane, h, d_value, d_prior, prior_is_log);
+    workers_select_phase(P, tree, nw, lane, h, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
+    whdr_store(&P.trees[tree], lane, h);
 }
 
 // ------------------------------------------- network search in one launch (few trees)

@@ -499,19 +499,24 @@ def one_tree_latency(torch, dev_index, sims=800):
         for shape in (15, 20):
             torch.manual_seed(0)
             ev = FusedNetEvaluator(PolicyValueNet(shape).eval(), shape, dev)
-            tb = sp.TreeBatch(1, shape, ev, cpuct=CPUCT, eps=0.25, nodes_per_tree=4 * sims + 64, device=dev_index)
-            try:
-                tb.make_move(np.array([shape * shape // 2], np.int32))
-                tb.simulate(32)
-                torch.cuda.synchronize(dev)
-                t0 = time.perf_counter()
-                tb.simulate(sims)
-                torch.cuda.synchronize(dev)
-                dt = time.perf_counter() - t0
-                out[f"ms_per_simulate_{shape}x{shape}"] = dt * 1e3
-                out[f"us_per_search_{shape}x{shape}"] = dt / sims * 1e6
-            finally:
-                tb.close()
+            # threads 0: one worker; 4 (general_config.py:72) and 8 (config.py:65): the reference's shipped settings,
+            # here concurrent workers in lock step (their leaves in one evaluator launch per step)
+            for threads in (0, 4, 8):
+                tb = sp.TreeBatch(1, shape, ev, cpuct=CPUCT, eps=0.25, threads=threads, nodes_per_tree=4 * sims + 64,
+                                  device=dev_index)
+                try:
+                    tb.make_move(np.array([shape * shape // 2], np.int32))
+                    tb.simulate(32)
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    tb.simulate(sims)
+                    torch.cuda.synchronize(dev)
+                    dt = time.perf_counter() - t0
+                    tag = f"{shape}x{shape}" + (f"_threads{threads}" if threads else "")
+                    out[f"ms_per_simulate_{tag}"] = dt * 1e3
+                    out[f"us_per_search_{tag}"] = dt / sims * 1e6
+                finally:
+                    tb.close()
     except Exception as e:
         out["error"] = f"{type(e).__name__}: {e}"
     return out

@@ -47,7 +47,11 @@ template <int S> struct W43Geo {
     static_assert(S >= 13 && S <= 16, "a 4x4 grid of tiles; what a patch reads past the board is zero or finite");
     static constexpr int LDS_BYTES = (G::BUF + 64) * 4; // + the zero tail behind the last plane
     static constexpr int WGS0 = (160 * 1024 - 2048) / (LDS_BYTES + 256); // positions per CU: eight at 15x15, seven at 16x16
+#ifdef AZ_W43_WGS // (experiments: fewer positions per CU)
+    static constexpr int WGS = AZ_W43_WGS;
+#else
     static constexpr int WGS = WGS0 > 8 ? 8 : WGS0;
+#endif
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -78,6 +82,31 @@ template <class T> __device__ __forceinline__ void w43_at(T m0, T m1, T m2, T m3
     y1 = w43_fma(k2, s, q);
     y2 = w43_fma(k4, r, p);
     y3 = w43_fma(k8, s, q) + m5;
+}
+
+// The parked trunk output.  VEC: tile R, row a of the lane = four consecutive floats, one 16-byte private-memory
+// access per tile row (fz is a multiple of four the compiler cannot see through); else one 4-byte access per cell.
+// Measured per 8192 positions, vector against scalar: 13x13 0.303 / 0.310 ms, 20x20 0.612 / 0.634 ms, but
+// 15x15 0.319 / 0.315 ms (twice, same box): the form is chosen per board size (w43_park_vec).
+template <int S> constexpr bool w43_park_vec() { return S != 15 && S != 16; }
+template <bool VEC> __device__ __forceinline__ void w43_park(float *fc, int fz, int R, int a, const float (&row)[4])
+{
+    if constexpr (VEC) {
+        *reinterpret_cast<f32x4 *>(__builtin_assume_aligned(fc + fz + R * 16 + a * 4, 16)) = (f32x4){row[0], row[1], row[2], row[3]};
+    } else {
+#pragma unroll
+        for (int b = 0; b < 4; b++) fc[fz + (a * 4 + b) * 4 + R] = row[b];
+    }
+}
+template <bool VEC> __device__ __forceinline__ void w43_unpark(const float *fc, int fz, int R, int a, float (&row)[4])
+{
+    if constexpr (VEC) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(fc + fz + R * 16 + a * 4, 16));
+        row[0] = v[0]; row[1] = v[1]; row[2] = v[2]; row[3] = v[3];
+    } else {
+#pragma unroll
+        for (int b = 0; b < 4; b++) row[b] = fc[fz + (a * 4 + b) * 4 + R];
+    }
 }
 
 // Stores (wr), adds up (sum) or parks (keep) the 4x4 outputs y[a][b] of the lane's R-th tile (tile row kq, tile
@@ -123,9 +152,7 @@ __device__ __forceinline__ void w43_emit(float *buf, int cob, int kq, float (&y)
     }
     if (keep) {
 #pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) fc[fz + (a * 4 + b) * 4 + R] = y[a][b];
+        for (int a = 0; a < 4; a++) w43_park<w43_park_vec<S>()>(fc, fz, R, a, y[a]);
     }
 }
 
@@ -142,9 +169,11 @@ template <int S> __device__ __forceinline__ void w43_restore(float *buf, int lan
 #pragma unroll
         for (int a = 0; a < 4; a++) {
             const int ro = w43_row_offset<S>(a, kq);
+            float row[4];
+            w43_unpark<w43_park_vec<S>()>(fc, fz, r, a, row);
 #pragma unroll
             for (int b = 0; b < 4; b++)
-                if (4 * r + b < S) buf[cob + ro + 4 * r + b] = fc[fz + (a * 4 + b) * 4 + r];
+                if (4 * r + b < S) buf[cob + ro + 4 * r + b] = row[b];
         }
 }
 
@@ -346,7 +375,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #endif
     // The trunk output, which both branches start from, is parked in private memory while the value branch owns the
     // buffer; indexed through a value the compiler cannot see through, so that the array really lives in memory.
-    float fc[64];
+    __attribute__((aligned(16))) float fc[64];
     int fz;
     asm volatile("s_mov_b32 %0, 0" : "=s"(fz));
     constexpr int PPL = (G::SIZE + 63) / 64; // pixels this lane loads, gathers and stores: lane, lane + 64, ...
@@ -552,9 +581,7 @@ __device__ __forceinline__ void w43t_emit(float *buf, int co, unsigned T, float 
     }
     if (keep) {
 #pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) fc[fz + (a * 4 + b) * 4 + R] = y[a][b];
+        for (int a = 0; a < 4; a++) w43_park<w43_park_vec<S>()>(fc, fz, R, a, y[a]);
     }
 }
 
@@ -573,17 +600,22 @@ template <int S> __device__ __forceinline__ void w43t_restore(float *buf, int wa
             if constexpr (W::EXACT) {
                 float *c = buf + co * G::PS + (int)((4 * ty + 1) * G::ROW + 4 * tx + 1);
 #pragma unroll
-                for (int a = 0; a < 4; a++)
+                for (int a = 0; a < 4; a++) {
+                    float row[4];
+                    w43_unpark<w43_park_vec<S>()>(fc, fz, r, a, row);
 #pragma unroll
-                    for (int b = 0; b < 4; b++) c[a * G::ROW + b] = fc[fz + (a * 4 + b) * 4 + r];
+                    for (int b = 0; b < 4; b++) c[a * G::ROW + b] = row[b];
+                }
             } else { // (cells outside the board were parked as zeros: folded onto the halo as in w43t_emit)
                 const int rows_in = S - 4 * (int)ty, cols_in = S - 4 * (int)tx;
                 float *c = buf + co * G::PS + G::ROW + 1;
 #pragma unroll
                 for (int a = 0; a < 4; a++) {
                     const int ra = (a < rows_in ? 4 * (int)ty + a : S) * G::ROW;
+                    float row[4];
+                    w43_unpark<w43_park_vec<S>()>(fc, fz, r, a, row);
 #pragma unroll
-                    for (int b = 0; b < 4; b++) c[ra + (b < cols_in ? 4 * (int)tx + b : S)] = fc[fz + (a * 4 + b) * 4 + r];
+                    for (int b = 0; b < 4; b++) c[ra + (b < cols_in ? 4 * (int)tx + b : S)] = row[b];
                 }
             }
         }
@@ -693,7 +725,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     __syncthreads();
 
-    float fc[64]; // the trunk output of this wavefront's tiles, parked in private memory while the value branch owns the buffer
+    __attribute__((aligned(16))) float fc[64]; // the trunk output of this wavefront's tiles, parked in private memory while the value branch owns the buffer
     int fz;
     asm volatile("s_mov_b32 %0, 0" : "=s"(fz));
     constexpr int PPL = (G::SIZE + W::NTHR - 1) / W::NTHR; // pixels this thread loads: tid, tid + 128, ...

@@ -96,7 +96,7 @@ struct AzParams {
 
 struct AzFusedArgs {
     int waves_per_tree;  // 0 = let the launcher choose from the number of trees
-    int lean;            // kernel form for many trees (see k_simulate_fused): 0 / 1, -1 = let the launcher choose
+    int lean;            // kernel form (see simulate_fused_body): 0 early load / 1 lean / 2 compact, -1 = let the launcher choose
     int n_total;         // searches per tree in this launch
     int per_worker;      // noise stream restarts every per_worker searches
     int eval_kind;

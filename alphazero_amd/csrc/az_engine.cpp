@@ -535,7 +535,7 @@ int az_simulate_fused(az_engine *e, int n, int eval_kind, float const_prior, flo
     }
     if (const char *w = getenv("AZ_WAVES_PER_TREE")) A.waves_per_tree = atoi(w); // tuning override
     A.lean = -1;
-    if (const char *w = getenv("AZ_FUSED_LEAN")) A.lean = atoi(w) != 0; // tuning / test override of the kernel form
+    if (const char *w = getenv("AZ_FUSED_LEAN")) A.lean = atoi(w) < 0 ? -1 : (atoi(w) > 2 ? 2 : atoi(w)); // tuning / test override of the kernel form
     A.n_total = th_num * per;
     A.per_worker = per;
     A.eval_kind = eval_kind;

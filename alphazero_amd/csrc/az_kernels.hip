@@ -485,7 +485,9 @@ __device__ __forceinline__ double div_by_cached(double t, double b, double rinv)
     return q;
 }
 // `u` keeps every action's score (-inf for an illegal one) for the next-pick hint.
-template <int E>
+// NP1_CACHED = false: (double)(N + 1) is formed from the visit count each time instead of being carried in
+// registers (the same value: the conversion of a small integer is exact).
+template <int E, bool NP1_CACHED = true>
 __device__ __forceinline__ void scan_root(const NodeRegs<E> &R, const RootCache<E> &C, double sq, unsigned occ,
                                           int tid, Cand &c, double (&uk)[E])
 {
@@ -494,11 +496,12 @@ __device__ __forceinline__ void scan_root(const NodeRegs<E> &R, const RootCache<
     for (int k = 0; k < E; k++) {
         const int a = tid * E + k;
         const bool valid = (a < SIZE) && !((occ >> k) & 1u);
+        const double np1 = NP1_CACHED ? C.np1[k] : (double)(R.n[k] + 1);
         // No N == 0 branch: there q = 0 and np1 = 1, and 0 + t/1 is t itself
         // (t >= 0), so the one expression serves both cases of node.cpp:105-108
         // and the four divisions of a thread overlap instead of running as
         // four separate masked blocks.
-        const double u = C.q[k] + div_by_cached(C.cp[k] * sq, C.np1[k], C.rinv[k]);
+        const double u = C.q[k] + div_by_cached(C.cp[k] * sq, np1, C.rinv[k]);
         uk[k] = valid ? u : -INFINITY;
         cand_take(c, valid && u > c.u, u, k, R.n[k], R.link[k], R.w[k]);
     }
@@ -771,9 +774,13 @@ __device__ __forceinline__ int pop_free(const AzParams &P, size_t tbase, int &fr
 #ifndef AZ_FUSED_ATTR
 #define AZ_FUSED_ATTR
 #endif
-template <int WPT, int EVAL, int MIX, bool LEAN = false>
-__global__ __launch_bounds__(64 * WPT) AZ_FUSED_ATTR void k_simulate_fused(AzParams P, AzFusedArgs A)
+// FORM 2 (compact): the lean form without the cached N + 1 of the root's actions, compiled for four wavefronts per
+//   SIMD (128 registers): for launches of many more trees than SIMDs, where the wavefronts in flight hide each
+//   other's latencies.
+template <int WPT, int EVAL, int MIX, int FORM>
+__device__ __forceinline__ void simulate_fused_body(const AzParams &P, const AzFusedArgs &A)
 {
+    constexpr bool LEAN = FORM >= 1, COMPACT = FORM == 2;
     constexpr bool EARLY_LOAD = !LEAN;
     constexpr int TAB = LEAN ? SQ_TAB_LEAN : SQ_TAB;
     constexpr int T = 64 * WPT;
@@ -824,8 +831,8 @@ __global__ __launch_bounds__(64 * WPT) AZ_FUSED_ATTR void k_simulate_fused(AzPar
 #pragma unroll
         for (int k = 0; k < E; k++) {
             C.cp[k] = P.cpuct * R.p[k];
-            C.np1[k] = (double)(R.n[k] + 1);
-            C.rinv[k] = 1. / C.np1[k];
+            if constexpr (!COMPACT) C.np1[k] = (double)(R.n[k] + 1);
+            C.rinv[k] = 1. / (double)(R.n[k] + 1);
             C.q[k] = R.n[k] != 0 ? R.w[k] / (double)R.n[k] : 0.;
         }
     }
@@ -868,7 +875,8 @@ __global__ __launch_bounds__(64 * WPT) AZ_FUSED_ATTR void k_simulate_fused(AzPar
 #pragma unroll
             for (int k = 0; k < E; k++) {
                 R.n[k] = 0; R.link[k] = 0; R.w[k] = 0.;
-                C.cp[k] = P.cpuct * R.p[k]; C.np1[k] = 1.; C.rinv[k] = 1.; C.q[k] = 0.;
+                C.cp[k] = P.cpuct * R.p[k]; C.rinv[k] = 1.; C.q[k] = 0.;
+                if constexpr (!COMPACT) C.np1[k] = 1.;
             }
             root_n = 0;
             sq_root = sqrt_from_table<TAB>(0, s_sqrt);
@@ -897,7 +905,7 @@ __global__ __launch_bounds__(64 * WPT) AZ_FUSED_ATTR void k_simulate_fused(AzPar
         {
             Cand c;
             double uk[E];
-            scan_root<E>(R, C, sq_root, s.occ, tid, c, uk);
+            scan_root<E, !COMPACT>(R, C, sq_root, s.occ, tid, c, uk);
             pk = finish_pick<WPT, E>(c, tid, s_slots, phase);
             if constexpr (WPT == 1 && EARLY_LOAD)
                 if (AZ_LIKELY(pk.a >= 0)) runner_up<E>(R, uk, pk.a, tid, pf_link, pf_n);
@@ -922,7 +930,7 @@ __global__ __launch_bounds__(64 * WPT) AZ_FUSED_ATTR void k_simulate_fused(AzPar
                 const int onei = hit ? 1 : 0;
                 const double one = hit ? 1. : 0.;
                 R.n[k] += onei;
-                C.np1[k] += one;
+                if constexpr (!COMPACT) C.np1[k] += one;
                 R.w[k] -= one;
             }
         }
@@ -1065,7 +1073,7 @@ __global__ __launch_bounds__(64 * WPT) AZ_FUSED_ATTR void k_simulate_fused(AzPar
                 if (k == slot_of<E>(root_a)) {
                     R.w[k] += (double)value + 1.;
                     C.q[k] = R.w[k] / (double)R.n[k];
-                    C.rinv[k] = 1. / C.np1[k];
+                    C.rinv[k] = 1. / (COMPACT ? (double)(R.n[k] + 1) : C.np1[k]);
                 }
         }
         n_sims++;
@@ -1091,6 +1099,17 @@ __global__ __launch_bounds__(64 * WPT) AZ_FUSED_ATTR void k_simulate_fused(AzPar
         Tr->stats[2] += n_term;
         Tr->stats[3] += n_sel;
     }
+}
+template <int WPT, int EVAL, int MIX, bool LEAN = false>
+__global__ __launch_bounds__(64 * WPT) AZ_FUSED_ATTR void k_simulate_fused(AzParams P, AzFusedArgs A)
+{
+    simulate_fused_body<WPT, EVAL, MIX, LEAN ? 1 : 0>(P, A);
+}
+// the compact form: register budget of four wavefronts per SIMD
+template <int EVAL, int MIX>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_simulate_fused_c(AzParams P, AzFusedArgs A)
+{
+    simulate_fused_body<1, EVAL, MIX, 2>(P, A);
 }
 
 // --------------------------------------------------------------- step: select
@@ -2106,6 +2125,10 @@ int pick_wpt(const AzParams &P, const AzFusedArgs &A)
     return wpt;
 }
 
+// trees per SIMD from which the compact form is launched (it needs more wavefronts in flight than the lean form's three)
+#ifndef AZ_COMPACT_MIN_WAVES
+#define AZ_COMPACT_MIN_WAVES 4
+#endif
 int l_simulate_fused(const AzParams &P, const AzFusedArgs &A, void *stream)
 {
     const int wpt = pick_wpt(P, A);
@@ -2124,10 +2147,18 @@ int l_simulate_fused(const AzParams &P, const AzFusedArgs &A, void *stream)
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         return 4 * cus;
     }();
-    const bool lean = A.lean >= 0 ? A.lean != 0 : (!uniform || P.n_trees > simds);
+    // form: 0 = early load, 1 = lean, 2 = compact (four wavefronts per SIMD): AzFusedArgs::lean overrides the choice
+    // Measured on MI355X at 8192 trees (eight per SIMD), compact against lean: uniform evaluator 792 against 771 M sims/s;
+    // hash evaluator (whose 64-bit integer arithmetic spills 12 - 24 registers at 128) 543 against 580 M at 15x15 and 170
+    // against 276 M at 20x20: the compact form is the launcher's choice for the uniform evaluator only.
+    const int form = A.lean >= 0 ? A.lean
+                     : !uniform ? 1
+                     : P.n_trees >= AZ_COMPACT_MIN_WAVES * simds ? 2
+                     : P.n_trees > simds ? 1 : 0;
 #define AZ_FUSED_LAUNCH(EV, MX)                                                                                   \
     do {                                                                                                          \
-        if (lean) hipLaunchKernelGGL((k_simulate_fused<1, EV, MX, true>), grid, dim3(64), 0, st, P, A);           \
+        if (form == 2) hipLaunchKernelGGL((k_simulate_fused_c<EV, MX>), grid, dim3(64), 0, st, P, A);             \
+        else if (form == 1) hipLaunchKernelGGL((k_simulate_fused<1, EV, MX, true>), grid, dim3(64), 0, st, P, A); \
         else hipLaunchKernelGGL((k_simulate_fused<1, EV, MX, false>), grid, dim3(64), 0, st, P, A);               \
     } while (0)
     if (uniform && identity_mix) AZ_FUSED_LAUNCH(AZ_EVAL_UNIFORM, 0);

@@ -156,14 +156,14 @@ def test_fused_more_visits_than_the_sqrt_table_holds():
     _play_fused(9, B=2, sims=2600, plies=2, ev_kind="hash", eps=0.0, cpuct=4.0, nodes=2600 * 3)
 
 
-@pytest.mark.parametrize("lean", ["0", "1"])
+@pytest.mark.parametrize("lean", ["0", "1", "2"])
 @pytest.mark.parametrize("S,B,sims,plies,ev,eps,cpuct", [(15, 10, 300, 4, "uniform", 0.25, 4.0), (15, 10, 300, 4, "hash", 0.0, 4.0),
                                                        (20, 6, 200, 3, "hash", 0.25, 4.0), (7, 8, 150, 30, "hash", 0.0, 2.0),
                                                        (15, 3, 800, 3, "uniform", 0.0, 4.0), (20, 2, 300, 2, "uniform", 0.0, 0.0)])
 def test_fused_kernel_forms_match_the_oracle(S, B, sims, plies, ev, eps, cpuct, lean, monkeypatch):
     """The launcher picks the fused kernel's form by evaluator and tree count (early child load + large
-    sqrt table for about one wavefront per SIMD, the lean form for many trees); AZ_FUSED_LEAN forces
-    one: both forms against the oracle on either evaluator, with and without noise, past the lean
+    sqrt table for about one wavefront per SIMD, the lean form for many trees, the compact form -- 128 registers,
+    four wavefronts per SIMD -- for very many); AZ_FUSED_LEAN forces one: every form against the oracle on either evaluator, with and without noise, past the lean
     form's 512-entry sqrt table, down a path deeper than 64 levels and through finished games."""
     monkeypatch.setenv("AZ_FUSED_LEAN", lean)
     _play_fused(S, B=B, sims=sims, plies=plies, ev_kind=ev, eps=eps, cpuct=cpuct)

@@ -30,15 +30,22 @@ def main():
     while time.time() - t0 < args.seconds:
         S = int(rng.integers(5, 21))
         sims = int(rng.integers(20, 700))
-        os.environ["AZ_FUSED_LEAN"] = str(int(rng.integers(0, 2)))
+        os.environ["AZ_FUSED_LEAN"] = str(int(rng.integers(0, 3)))
         TS._play_fused(S, B=int(rng.integers(1, 6)), sims=sims, plies=int(rng.integers(2, 6)),
                        ev_kind=str(rng.choice(["uniform", "hash"])), eps=float(rng.choice([0.0, 0.1, 0.25, 1.0])),
                        cpuct=float(rng.choice([0.0, 0.5, 4.0, 10.0])), nodes=sims * 8 + 64, seed=int(rng.integers(1, 1000)))
         n_fused += 1
         if n_fused % 8 == 0:
             B, S2 = int(rng.integers(2, 200)), int(rng.choice([5, 6, 7, 9, 13, 14, 15, 16, 17, 19, 20]))
-            TC.test_simulate_net_position_mask_with_idle_and_terminal_leaves(B, S2, int(rng.integers(2, 6)) if S2 != 5 else 24,
-                                                                             bool(rng.integers(0, 2)))
+            from alphazero_amd import engine as E
+            from conftest import NET_FORMS
+            lib = E.load_library()
+            try:
+                TC.test_simulate_net_position_mask_with_idle_and_terminal_leaves(
+                    B, S2, int(rng.integers(2, 6)) if S2 != 5 else 24, bool(rng.integers(0, 2)),
+                    lambda form: lib.az_net_set_form(NET_FORMS.get(form, form)))
+            finally:
+                lib.az_net_set_form(0)
             n_net += 1
         print(f"\r{n_fused} fused, {n_net} network configurations ok", end="", flush=True)
     print()

@@ -87,7 +87,8 @@ struct AzParams {
     unsigned long long *stamps; // diagnostic builds only (AZ_STAMPS): [n_trees][8] cycle sums, else null
     const double *noise; // [noise_rows][SP] or null
     int noise_rows;
-    int n_trees;
+    int n_trees;      // trees of the engine; for a launch over a group of trees: the trees of the group (the grid)
+    int tree_base;    // first tree of the group a step kernel is launched for (its blocks handle tree_base + blockIdx.x)
     int cap;
     int path_cap;
     double cpuct;

@@ -1202,7 +1202,8 @@ __device__ __forceinline__ void select_body(const AzParams &P, int tree, int out
 __global__ __launch_bounds__(64) AZ_STEP_OCC void k_select(AzParams P, float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask,
                                                unsigned *d_clear_mask)
 {
-    select_body(P, blockIdx.x, blockIdx.x, threadIdx.x, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
+    const int tree = blockIdx.x + P.tree_base;
+    select_body(P, tree, tree, threadIdx.x, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
 }
 
 // ------------------------------------------------------ step: expand + backup
@@ -1289,7 +1290,8 @@ __device__ __forceinline__ void expand_backup_body(const AzParams &P, int tree, 
 __global__ __launch_bounds__(64) void k_expand_backup(AzParams P, const float *d_value, const float *d_prior,
                                                        int prior_is_log)
 {
-    expand_backup_body(P, blockIdx.x, blockIdx.x, threadIdx.x, d_value, d_prior, prior_is_log);
+    const int tree = blockIdx.x + P.tree_base;
+    expand_backup_body(P, tree, tree, threadIdx.x, d_value, d_prior, prior_is_log);
 }
 // The backup of one search step and the select of the next in one launch (the network search's inner
 // loop: one launch and one pass over the tree header less per step).
@@ -1297,8 +1299,9 @@ __global__ __launch_bounds__(64) AZ_STEP_OCC void k_backup_select(AzParams P, co
                                                        int prior_is_log, float *d_boards, int *d_leaf_kind,
                                                        unsigned *d_expand_mask, unsigned *d_clear_mask)
 {
-    expand_backup_body(P, blockIdx.x, blockIdx.x, threadIdx.x, d_value, d_prior, prior_is_log);
-    select_body(P, blockIdx.x, blockIdx.x, threadIdx.x, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
+    const int tree = blockIdx.x + P.tree_base;
+    expand_backup_body(P, tree, tree, threadIdx.x, d_value, d_prior, prior_is_log);
+    select_body(P, tree, tree, threadIdx.x, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
 }
 
 // ------------------------------------------------ concurrent workers, lock step
@@ -1630,7 +1633,7 @@ __device__ __forceinline__ void workers_backup_phase(const AzParams &P, int tree
 __global__ __launch_bounds__(64) void k_workers_select(AzParams P, int nw, float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask,
                                                        unsigned *d_clear_mask)
 {
-    const int tree = blockIdx.x, lane = threadIdx.x;
+    const int tree = blockIdx.x + P.tree_base, lane = threadIdx.x;
     WHdr h;
     whdr_load(&P.trees[tree], lane, h);
     workers_select_phase(P, tree, nw, lane, h, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
@@ -1638,7 +1641,7 @@ __global__ __launch_bounds__(64) void k_workers_select(AzParams P, int nw, float
 }
 __global__ __launch_bounds__(64) void k_workers_backup(AzParams P, int nw, const float *d_value, const float *d_prior, int prior_is_log)
 {
-    const int tree = blockIdx.x, lane = threadIdx.x;
+    const int tree = blockIdx.x + P.tree_base, lane = threadIdx.x;
     WHdr h;
     whdr_load(&P.trees[tree], lane, h);
     workers_backup_phase(P, tree, nw, lane, h, d_value, d_prior, prior_is_log);
@@ -1648,7 +1651,7 @@ __global__ __launch_bounds__(64) void k_workers_backup_select(AzParams P, int nw
                                                               int prior_is_log, float *d_boards, int *d_leaf_kind,
                                                               unsigned *d_expand_mask, unsigned *d_clear_mask)
 {
-    const int tree = blockIdx.x, lane = threadIdx.x;
+    const int tree = blockIdx.x + P.tree_base, lane = threadIdx.x;
     WHdr h;
     whdr_load(&P.trees[tree], lane, h);
     workers_backup_phase(P, tree, nw, lane, h, d_value, d_prior, prior_is_log);

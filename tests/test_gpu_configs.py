@@ -148,6 +148,45 @@ def test_simulate_net_position_mask_with_idle_and_terminal_leaves(B, S, plies, o
     b.close()
 
 
+@pytest.mark.parametrize("B,S,threads,groups", [(200, 15, 0, "3"), (97, 9, 0, "2"), (200, 15, 4, "4"), (70, 20, 3, "2"), (1030, 13, 0, "4")])
+def test_simulate_net_tree_groups_do_not_change_results(B, S, threads, groups, monkeypatch, net_form):
+    """az_simulate_net may split the trees into groups that run on streams of their own (so that one group's tree
+    kernels overlap the other's evaluation); trees are independent, so every statistic is the one-group result.
+    Uneven splits, fewer 32-tree blocks than groups, sequential and concurrent workers."""
+    import torch
+    from alphazero_amd import engine as E
+
+    sims, plies, size = 24, 2, S * S
+    _, ev = _fused(S, seed=7)
+    stream = torch.cuda.current_stream().cuda_stream
+    # (one kernel form for every batch size: left to itself az_net_eval gives small batches a kernel of their own,
+    # whose float32 sums round differently; the engine only forms groups far above those sizes)
+    net_form("w43" if S >= 13 else "direct")
+    results = []
+    for g in ("1", groups):
+        monkeypatch.setenv("AZ_NET_GROUPS", g)
+        monkeypatch.setenv("AZ_NET_SEARCH", "0")
+        e = E.Engine(B, S, nodes_per_tree=(sims + 8) * plies + 64, cpuct=4.0)
+        e.set_alpha_default()
+        e.set_eps(0.25)
+        e.set_threads(threads)
+        e.set_noise_table(np.random.default_rng(4).dirichlet(np.full(size, e.get_alpha()), size=sims + 2))
+        e.make_move(np.array([O.opening(size, 7 * t + 1)[0] for t in range(B)], np.int32))
+        e.set_active((np.arange(B) % 7 != 3).astype(np.uint8))
+        out = []
+        for ply in range(plies):
+            e.simulate_net(sims, ev.params.data_ptr(), ev.fused_layers, stream)
+            counts, root_n = e.get_counts()
+            out.append((counts.copy(), root_n.copy(), e.get_stats(), [e.get_node(t, [])[2].copy() for t in (0, B // 2 + (B // 2 % 7 == 3), B - 1 - ((B - 1) % 7 == 3))]))
+            e.make_move(np.where(root_n > 0, counts.argmax(axis=1), -1).astype(np.int32))
+        results.append(out)
+        e.close()
+    for a, b in zip(*results):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+        assert all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
+        assert a[1].max() > 0
+
+
 def test_simulate_net_matches_oracle():
     """The engine-driven network search against the CPU oracle, whose predictor returns
     what the fused kernel computes for the position it is asked about (batch of one):

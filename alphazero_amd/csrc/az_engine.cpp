@@ -88,7 +88,7 @@ struct az_engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // streams of the tree groups of az_simulate_net beyond the first (which runs on the caller's stream), and the
     // events that tie them to it
-    hipStream_t aux_streams[3] = {nullptr, nullptr, nullptr};
+    hipStream_t aux_streams[3] = {nullptr, nullptr, nullptr}; // (the device's shared ones, see device_aux_streams)
     int n_aux_streams = 0;
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> ev_slots; // [2 * slot + end] for az_timing_mark, created on first use
@@ -139,6 +139,29 @@ int resolve_scratch(int device)
     if (!ptr) return fail(AZ_ERR_HIP, "hipGetSymbolAddress returned a null address");
     g_scratch_ptr[device] = static_cast<char *>(ptr);
     return AZ_OK;
+}
+
+// The streams the tree groups of az_simulate_net run on beside the caller's: ONE set per device for all engines (a
+// process has few hardware queues -- four by default -- and streams beyond them share a queue, which would put a
+// group's work behind the very stream it is meant to overlap with), created with the device's first engine and kept
+// until the process ends.  As many as the AZ_NET_GROUPS override asks for, one by default.  Returns their number.
+int device_aux_streams(int device, hipStream_t (&out)[3])
+{
+    static hipStream_t pool[AZ_MAX_DEVICES][3] = {};
+    static int count[AZ_MAX_DEVICES] = {};
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    int want = 1;
+    if (const char *w = getenv("AZ_NET_GROUPS")) want = atoi(w) - 1;
+    want = want < 0 ? 0 : (want > 3 ? 3 : want);
+    while (count[device] < want) {
+        if (hipStreamCreateWithFlags(&pool[device][count[device]], hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        count[device]++;
+    }
+    for (int k = 0; k < 3; k++) out[k] = k < count[device] ? pool[device][k] : nullptr;
+    return count[device];
 }
 
 int check_tree(const az_engine *e, int tree)
@@ -285,11 +308,8 @@ int az_create(az_engine **out, int device, int n_trees, int shape, int nodes_per
         if (he == hipSuccess) he = hipEventCreate(&e->ev0);
         if (he == hipSuccess) he = hipEventCreate(&e->ev1);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
-        for (int k = 0; k < 3 && he == hipSuccess; k++) {
-            he = hipStreamCreateWithFlags(&e->aux_streams[k], hipStreamNonBlocking);
-            if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming);
-            if (he == hipSuccess) e->n_aux_streams = k + 1;
-        }
+        for (int k = 0; k < 3 && he == hipSuccess; k++) he = hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming);
+        if (he == hipSuccess) e->n_aux_streams = device_aux_streams(device, e->aux_streams);
         if (he != hipSuccess) {
             az_destroy(e);
             return fail(AZ_ERR_HIP, "engine initialisation failed: %s", hipGetErrorString(he));
@@ -314,10 +334,8 @@ void az_destroy(az_engine *e)
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < 3; k++)
         if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
-        if (e->aux_streams[k]) (void)hipStreamDestroy(e->aux_streams[k]);
-    }
     for (hipEvent_t ev : e->ev_slots)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &m : e->marks) (void)hipEventDestroy(m.done);

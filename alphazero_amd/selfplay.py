@@ -301,44 +301,58 @@ def all_records(games):
     return games
 
 
-def _assemble_records(torch, dev, slabs, outcome, shape):
+def _assemble_records(torch, dev, slabs, outcome, shape, pinned_bytes=256 << 20):
     """Training records of many games from per-half-move device slabs, assembled ON THE GPU.
     slabs: list of (step, side, pi [G,SIZE] device, board [G,2,S,S] device, played bool[G],
     game_of int64[G]); outcome[game] = the game's winner (0 / 1, anything else = draw).
     Returns (records, bounds): one structured array (sample_dtype) ordered by game, first
     player's records first, ply order inside a side, and the per-game slice bounds.  The
-    ordering keys are small host arrays; the record bytes move once, device -> host."""
+    ordering keys are small host arrays.  The list is CONSUMED: every slab is dropped as soon as
+    its records have been scattered to their final rows, so the peak device use is the slabs plus
+    one copy of the records (no stacked copy of all slabs), and the records reach the host
+    through a page-locked staging buffer of bounded size."""
     dt = sample_dtype(shape)
     size = shape * shape
     n_games = len(outcome)
     if not slabs:
         return np.zeros(0, dt), np.zeros(n_games + 1, np.int64)
-    G = slabs[0][2].shape[0]
     played = np.stack([sl[4] for sl in slabs])                       # [H, G]
     games = np.stack([sl[5] for sl in slabs])                        # [H, G]
-    h_idx, g_idx = np.nonzero(played)
+    h_idx, g_idx = np.nonzero(played)                                # row-major: slab by slab
     game = games[h_idx, g_idx]
     side = np.array([sl[1] for sl in slabs], np.int64)[h_idx]
     step = np.array([sl[0] for sl in slabs], np.int64)[h_idx]
     order = np.lexsort((step, side, game))
-    flat = torch.from_numpy((h_idx * G + g_idx)[order]).to(dev)
+    n = order.size
+    dest = np.empty(n, np.int64)                                     # final row of every record, in slab order
+    dest[order] = np.arange(n)
     won = outcome[game[order]]
     decided = (won == 0.0) | (won == 1.0)
     r = np.where(decided, np.where(won == side[order], 1.0, -1.0), 1e-3).astype(np.float32)  # src/self_play.py:188-200
-    n = flat.numel()
     out = torch.empty((n, 3 * size + 1), dtype=torch.float32, device=dev)
-    boards = torch.stack([sl[3] for sl in slabs]).reshape(len(slabs) * G, 2 * size)
-    out[:, :2 * size].copy_(boards.index_select(0, flat))
-    del boards
-    pis = torch.stack([sl[2] for sl in slabs]).reshape(len(slabs) * G, size)
-    out[:, 2 * size:3 * size].copy_(pis.index_select(0, flat))
-    del pis
+    per_slab = played.sum(axis=1)
+    at = 0
+    for h in range(len(slabs)):
+        k = int(per_slab[h])
+        _, _, pi, board, _, _ = slabs[h]
+        slabs[h] = None                                              # this slab's memory goes back once scattered
+        if k:
+            src = torch.from_numpy(g_idx[at:at + k]).to(dev)
+            dst = torch.from_numpy(dest[at:at + k]).to(dev)
+            out[:, :2 * size].index_copy_(0, dst, board.reshape(board.shape[0], 2 * size).index_select(0, src))
+            out[:, 2 * size:3 * size].index_copy_(0, dst, pi.index_select(0, src))
+        del pi, board
+        at += k
+    slabs.clear()
     out[:, 3 * size].copy_(torch.from_numpy(r))
-    # (through page-locked memory: a copy into pageable memory runs at a few GB/s, and the records of a
-    # large batch are gigabytes; the returned array keeps the page-locked tensor alive)
-    host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
-    host.copy_(out)
-    rec = host.numpy().view(dt).reshape(n)
+    rec = np.empty(n, dt)
+    flat = rec.view(np.float32).reshape(n, 3 * size + 1)
+    rows = max(1, int(pinned_bytes) // ((3 * size + 1) * 4))
+    stage = torch.empty((min(rows, max(n, 1)), 3 * size + 1), dtype=torch.float32, pin_memory=True)
+    for a in range(0, n, rows):
+        b = min(n, a + rows)
+        stage[:b - a].copy_(out[a:b])
+        flat[a:b] = stage[:b - a].numpy()
     bounds = np.searchsorted(game[order], np.arange(n_games + 1))
     return rec, bounds
 
@@ -396,12 +410,15 @@ def self_play_games_device(batch0, batch1, sims, tau, init_moves=(), rng=None):
     for side in (0, 1):
         for step, ((pi, board), alive_then) in enumerate(zip(slabs[side], played[side])):
             slab_list.append((step, side, pi, board, alive_then, np.arange(G, dtype=np.int64)))
+    slabs[0].clear()  # (the assembly drops each slab as it goes)
+    slabs[1].clear()
+    pi = board = None
     rec, bounds = _assemble_records(torch, dev, slab_list, np.asarray(winner, np.float32), S)
     return GameRecords(rec, bounds)
 
 
 def self_play_stream(batch0, batch1, sims, tau, n_games, init_moves=(), rng=None, flush_plies=None,
-                     device_record_bytes=48 << 30):
+                     device_record_bytes=None):
     """`n_games` games of `self_play_game` (src/self_play.py:134-202) on the G tree
     slots of the two batches, a finished game's slot being cleared and handed to
     the next game instead of idling until the longest game of the batch is over
@@ -415,7 +432,8 @@ def self_play_stream(batch0, batch1, sims, tau, n_games, init_moves=(), rng=None
     ends on an even half-step leaves its slot empty for one half-step.  `rng`
     supplies one uniform number per sampling game and half-step, in slot order.
     The per-half-step pi / board slabs stay on the GPU and are turned into records there at
-    the end (`_assemble_records`); `flush_plies` (or slabs beyond `device_record_bytes`)
+    the end (`_assemble_records`); `flush_plies` (or slabs beyond `device_record_bytes`, by
+    default a quarter of the device memory that is free when the call starts)
     selects the bounded-memory path that moves them to the host every so many half-steps.
     Returns the list of per-game record arrays in game order."""
     torch = batch0.torch
@@ -427,6 +445,8 @@ def self_play_stream(batch0, batch1, sims, tau, n_games, init_moves=(), rng=None
     dt = sample_dtype(S)
     d_act = torch.empty(G, dtype=torch.int32, device=dev)
     d_u = torch.zeros(G, dtype=torch.float64, device=dev)
+    if device_record_bytes is None:  # the assembly at the end needs one more copy of the records beside the slabs
+        device_record_bytes = torch.cuda.mem_get_info(dev)[0] // 4
 
     game_of = np.full(G, -1, np.int64)   # game played in each slot, -1 = none
     pair = np.zeros(G, np.int64)         # the game's pair index i (src/self_play.py:155)
@@ -514,6 +534,8 @@ def self_play_stream(batch0, batch1, sims, tau, n_games, init_moves=(), rng=None
         half += 1
     if not rec_parts:  # everything is still on the GPU: order and label the records there
         slab_list = [(step, step & 1, pi, board, played, games) for step, pi, board, played, games in slabs]
+        slabs.clear()  # (the assembly drops each slab as it goes)
+        pi = board = None
         rec, bounds = _assemble_records(torch, dev, slab_list, outcome, S)
         return GameRecords(rec, bounds)
     flush()

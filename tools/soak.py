@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Longer randomized differential run than the test suite's fixed-seed sweeps: the fused search
-(both kernel forms) and the network search's mask path against the oracle / the three-step path.
+(every kernel form) and the network search's mask path against the oracle / the three-step path,
+concurrent workers against the oracle's lock-step mode, the resident game loop against the
+host-stepped one.
 
     python tools/soak.py [--seconds 120] [--seed 1]
 """
@@ -24,9 +26,11 @@ def main():
     args = ap.parse_args()
     import test_gpu_search as TS
     import test_gpu_configs as TC
+    import test_gpu_workers as TW
+    import test_gpu_resident as TR
 
     rng = np.random.default_rng(args.seed)
-    t0, n_fused, n_net = time.time(), 0, 0
+    t0, n_fused, n_net, n_workers, n_resident = time.time(), 0, 0, 0, 0
     while time.time() - t0 < args.seconds:
         S = int(rng.integers(5, 21))
         sims = int(rng.integers(20, 700))
@@ -47,7 +51,15 @@ def main():
             finally:
                 lib.az_net_set_form(0)
             n_net += 1
-        print(f"\r{n_fused} fused, {n_net} network configurations ok", end="", flush=True)
+        if n_fused % 24 == 0:
+            TW.test_concurrent_workers_match_the_oracle_lockstep(int(rng.choice([7, 9, 13, 15, 20])), int(rng.integers(2, 9)),
+                                                                 int(rng.integers(3, 90)), float(rng.choice([0.0, 0.25])))
+            n_workers += 1
+        if n_fused % 48 == 0:
+            TR.test_resident_self_play_equals_stream_driver(float(rng.choice([0.0, 0.25])), int(rng.integers(-1, 6)),
+                                                            int(rng.integers(1, 6)), tuple(int(x) for x in rng.choice(49, size=int(rng.integers(0, 3)), replace=False)))
+            n_resident += 1
+        print(f"\r{n_fused} fused, {n_net} network, {n_workers} worker, {n_resident} resident configurations ok", end="", flush=True)
     print()
 
 

@@ -526,6 +526,40 @@ def one_tree_latency(torch, dev_index, sims=800):
     return out
 
 
+def workers_by_width(torch, dev_index, shape=SHAPE, sims=400):
+    """threads > 1 as concurrent workers (the reference's callers set THREADS = 4, general_config.py:72): the network
+    search of one move at several batch widths with one worker and with four in lock step (their leaves share the
+    evaluator launch, so a batch that does not fill the evaluator's grid fills it four times better)."""
+    out = {"workload": f"{shape}x{shape}, reference net (seed 0), eps=0.25, cpuct=4, one simulate({sims}) per line; "
+                       "threads 0 = one worker, 4 = four concurrent workers in lock step", "unit": "sims/s", "lines": []}
+    try:
+        from alphazero_amd import selfplay as sp
+        from alphazero_amd.evaluator import FusedNetEvaluator
+        from alphazero_amd.model import PolicyValueNet
+
+        dev = torch.device("cuda", dev_index)
+        torch.manual_seed(0)
+        ev = FusedNetEvaluator(PolicyValueNet(shape).eval(), shape, dev)
+        for trees in (8192, 2048, 512):
+            for threads in (0, 4):
+                tb = sp.TreeBatch(trees, shape, ev, cpuct=CPUCT, eps=0.25, threads=threads, nodes_per_tree=sims + 64, device=dev_index)
+                try:
+                    tb.make_move((np.arange(trees) % (shape * shape)).astype(np.int32))
+                    tb.simulate(16)
+                    tb.eng.reset_stats()
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    tb.simulate(sims)
+                    torch.cuda.synchronize(dev)
+                    dt = time.perf_counter() - t0
+                    out["lines"].append({"trees": trees, "threads": threads, "value": tb.eng.get_stats()["sims"] / dt, "ms": dt * 1e3})
+                finally:
+                    tb.close()
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
 def config4_share(torch, E, dev_index):
     """One GPU's share of config 4 (65,536 games of 20x20 over 8 GPUs = 8192 per GPU):
     the network-evaluated search at that width; 200 search steps timed."""
@@ -731,7 +765,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--only", default=None,
                     help="run one secondary workload alone and print its record (for profiling): "
-                         + ", ".join(list(HASH_WORKLOADS) + ["config3", "config4_share", "config3_games", "config3_stream", "config3_stream_host", "config5_share", "config5_share_host", "config1_one_tree"]))
+                         + ", ".join(list(HASH_WORKLOADS) + ["config3", "config4_share", "config3_games", "config3_stream", "config3_stream_host", "config5_share", "config5_share_host", "config1_one_tree", "concurrent_workers"]))
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -780,6 +814,7 @@ def main():
                else secondary_games(torch, dev_index, "arena", games=32768, slots=16384, resident=True) if args.only == "config5_share"
                else secondary_games(torch, dev_index, "arena") if args.only == "config5_share_host"
                else one_tree_latency(torch, dev_index) if args.only == "config1_one_tree"
+               else workers_by_width(torch, dev_index) if args.only == "concurrent_workers"
                else secondary_hash(torch, E, dev_index, args.only, *HASH_WORKLOADS[args.only], traffic))
         print(json.dumps(rec), flush=True)
         return
@@ -865,6 +900,7 @@ def main():
                 "config3_stream_host": secondary_games(torch, dev_index, "selfplay", games=16384, slots=8192),
                 "config5_share_host": secondary_games(torch, dev_index, "arena"),
                 "config1_one_tree": one_tree_latency(torch, dev_index),
+                "concurrent_workers": workers_by_width(torch, dev_index),
             }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -246,3 +246,49 @@ def test_simulate_net_lock_step_matches_the_oracle():
         for t, a in zip(trees, act):
             t.make_move(int(a))
     eng.close()
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("S,T,sims", [(15, 4, 48), (20, 8, 24)])
+def test_concurrent_workers_at_full_width_against_the_oracle_on_sampled_trees(S, T, sims):
+    """8192 trees with several concurrent workers each (the width the self-play drivers run at, where the
+    trees are split into groups on two streams): sampled trees bit-exact against the oracle in lock-step
+    mode through three moves, and the bookkeeping invariants on every tree."""
+    from alphazero_amd import selfplay as sp
+
+    G, plies, size = 8192, 3, S * S
+    batch = sp.TreeBatch(G, S, ExactTorchEvaluator(), cpuct=4.0, eps=0.25, threads=T, nodes_per_tree=(sims + 2 * T) * plies + 64)
+    noise = np.random.default_rng(S * T).dirichlet(np.full(size, batch.eng.get_alpha()), size=sims + 2)
+    batch.set_noise_table(noise)
+    sample = [0, 1, 31, 32, 2047, 4095, 4096, 4097, 6143, 8160, 8191]
+    trees = {g: _oracle(S, T, 0.25) for g in sample}
+    first = np.array([O.opening(size, g)[0] for g in range(G)], np.int32)
+    batch.make_move(first)
+    for g, ot in trees.items():
+        ot.make_move(int(first[g]))
+    oev = oracle_exact_evaluator(S)
+    carried = np.zeros(G, np.int64)
+    for ply in range(plies):
+        batch.simulate(sims)
+        counts, root_n = batch.eng.get_counts()
+        assert np.array_equal(counts.sum(axis=1), root_n)
+        raw = batch.eng.get_raw_boards().reshape(G, 2, size)
+        assert not np.any(counts[(raw[:, 0] + raw[:, 1]) > 0])
+        for g, ot in trees.items():
+            ot.simulate(sims, oev, noise)
+            assert root_n[g] == ot.root_n(), (ply, g)
+            assert np.array_equal(counts[g].astype(np.int64), ot.root_counts()), (ply, g)
+            got, want = batch.eng.get_node(g, []), ot.node_at([])
+            assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3]), (ply, g)
+            a = int(counts[g].argmax())
+            got, want = batch.eng.get_node(g, [a]), ot.node_at([a])
+            assert got[0] == want[0] and np.array_equal(got[1].astype(np.int64), want[1]) and np.array_equal(got[2], want[2]), (ply, g)
+        act = counts.argmax(axis=1).astype(np.int32)
+        batch.make_move(act)
+        for g, ot in trees.items():
+            ot.make_move(int(act[g]))
+    st = batch.eng.get_stats()
+    # workers that meet in a node another worker of the step expands back its value up without expanding
+    assert st["sims"] == G * plies * sims and st["sims"] * 0.9 < st["expansions"] + st["terminals"] <= st["sims"]
+    assert np.all(batch.eng.get_errors() == 0)
+    batch.close()

@@ -746,10 +746,18 @@ __device__ __forceinline__ int pop_free(const AzParams &P, size_t tbase, int &fr
         st_acc[6] |= (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) << 40; \
         st_acc[7] |= (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff) << 40; \
         for (int q = 0; q < 8; q++) P.stamps[(size_t)(tree) * 8 + q] = st_acc[q]; } } while (0)
+// (the worker kernels run once per search step: their sums ADD to what is there, the reader takes differences)
+#define STAMP_ADD(tree) do { if (lane == 0 && P.stamps) { \
+        for (int q = 0; q < 8; q++) P.stamps[(size_t)(tree) * 8 + q] += st_acc[q]; } } while (0)
+#define STAMP_PARAM , unsigned long long (&st_acc)[8], unsigned long long &st_t
+#define STAMP_ARG , st_acc, st_t
 #else
 #define STAMP_DECL
 #define STAMP(i) do { } while (0)
 #define STAMP_FLUSH(tree) do { } while (0)
+#define STAMP_ADD(tree) do { } while (0)
+#define STAMP_PARAM
+#define STAMP_ARG
 #endif
 
 // ------------------------------------------------------------ fused simulate
@@ -1324,12 +1332,31 @@ struct WHdr {
     unsigned n_sims, n_exp, n_term;
     unsigned long long n_sel;
     int words; // lane i: word i of the AzTree as loaded
+    int fbatch; // lane j: the j-th entry below the top of the free stack as it was at load time
+    int fpos;   // entries of fbatch handed out
 };
 static_assert(sizeof(AzTree) % 4 == 0 && sizeof(AzTree) <= 256, "the header fits one word per lane");
 static_assert(sizeof(AzWorker) == 32, "eight words per worker: eight workers per 64-lane chunk");
 #define AZ_HDR_WORD(words, field) __builtin_amdgcn_readlane(words, (int)(offsetof(AzTree, field) / 4))
-__device__ __forceinline__ void whdr_load(const AzTree *T, int lane, WHdr &h)
+__device__ __forceinline__ void whdr_free_batch(const AzParams &P, int tree, int lane, WHdr &h)
 {
+    const int idx = h.free_top - 1 - lane;
+    h.fbatch = idx >= 0 ? P.free_stack[(size_t)tree * P.cap + idx] : -1;
+    h.fpos = 0;
+}
+// the next free slot (the caller has checked free_top > 0).  A pop per created node would be a memory round trip
+// each; the 64 entries on top of the stack are requested once, right after the header.
+__device__ __forceinline__ int whdr_pop_free(const AzParams &P, int tree, int lane, WHdr &h)
+{
+    if (AZ_UNLIKELY(h.fpos == 64)) whdr_free_batch(P, tree, lane, h);
+    const int slot = __builtin_amdgcn_readlane(h.fbatch, h.fpos);
+    h.fpos++;
+    h.free_top--;
+    return slot;
+}
+__device__ __forceinline__ void whdr_load(const AzParams &P, int tree, int lane, WHdr &h)
+{
+    const AzTree *T = &P.trees[tree];
     h.words = lane < (int)(sizeof(AzTree) / 4) ? reinterpret_cast<const int *>(T)[lane] : 0;
     h.root = AZ_HDR_WORD(h.words, root);
     h.root_n = AZ_HDR_WORD(h.words, root_n);
@@ -1340,6 +1367,7 @@ __device__ __forceinline__ void whdr_load(const AzTree *T, int lane, WHdr &h)
     h.active = AZ_HDR_WORD(h.words, active);
     h.n_sims = h.n_exp = h.n_term = 0u;
     h.n_sel = 0ull;
+    whdr_free_batch(P, tree, lane, h);
 }
 __device__ __forceinline__ void whdr_store(AzTree *T, int lane, const WHdr &h)
 {
@@ -1382,7 +1410,7 @@ __device__ __forceinline__ void wput(int &wr, int lane, int wi, int field, int v
 // worker (chunk position wi, index w) descends to its leaf
 __device__ __forceinline__ void wselect_body(const AzParams &P, int tree, int w, int wi, int nw, int lane, const WState &root_state,
                                              WHdr &h, int &wr, float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask,
-                                             unsigned *d_clear_mask)
+                                             unsigned *d_clear_mask STAMP_PARAM)
 {
     constexpr int E = EPL;
     const int out = tree * nw + w;
@@ -1409,7 +1437,9 @@ __device__ __forceinline__ void wselect_body(const AzParams &P, int tree, int w,
 #pragma unroll
             for (int k = 0; k < E; k++) { nd.n[k] = 0; nd.link[k] = 0; nd.w[k] = 0.; }
         }
+        STAMP(3);
         const Pick pk = select_pick<1, E>(nd, fresh, sqrt_node_n(nn, nullptr), s.occ, P.cpuct, lane, nullptr, phase);
+        STAMP(4);
         if (pk.a < 0) { err = AZ_ERR_NO_ACTION; break; }
         h.n_sel++;
         char *rec = rec_ptr(P, tree, cur);
@@ -1435,7 +1465,9 @@ __device__ __forceinline__ void wselect_body(const AzParams &P, int tree, int w,
             ax = P.aux[tbase + child];
             load_node<E>(P, tree, child, lane, false, nd);
         }
+        STAMP(5);
         state_move<E>(s, pk.a, lane);
+        STAMP(6);
         if (s.winner != -1.f) {
             kind = AZ_LEAF_TERMINAL;
             leaf_value = (s.winner == 0.f || s.winner == 1.f) ? 1.f : 0.f;
@@ -1443,14 +1475,13 @@ __device__ __forceinline__ void wselect_body(const AzParams &P, int tree, int w,
         }
         if (child < 0) { // Node::next_node creates the child now (node.cpp:126-134); this worker will expand it
             if (h.free_top == 0) { err = AZ_ERR_POOL_FULL; break; }
-            const int slot = uni(P.free_stack[tbase + h.free_top - 1]);
+            const int slot = whdr_pop_free(P, tree, lane, h);
             if (lane == owner_of<E>(pk.a)) reinterpret_cast<int *>(rec + OFF_LINK)[pk.a] = slot + 1;
             if (lane == 0) {
                 P.parent[tbase + slot] = cur;
                 P.order[tbase + h.n_order] = slot;
                 P.aux[tbase + slot] = -1;
             }
-            h.free_top--;
             h.n_order++;
             leaf_slot = slot;
             break;
@@ -1531,7 +1562,7 @@ __device__ __forceinline__ void wbackup_body(const AzParams &P, int tree, int w,
             expand = h.root < 0; // else an earlier worker of this step has expanded the root
             if (expand) {
                 if (h.free_top == 0) err = AZ_ERR_POOL_FULL;
-                else slot = uni(P.free_stack[tbase + h.free_top - 1]);
+                else slot = whdr_pop_free(P, tree, lane, h);
             }
         } else {
             expand = ax < 0; // else expanded by the worker that created it (node.cpp:30-33: nothing to do)
@@ -1559,7 +1590,6 @@ __device__ __forceinline__ void wbackup_body(const AzParams &P, int tree, int w,
                 }
                 h.root = slot;
                 h.root_n = 0;
-                h.free_top--;
                 h.n_order++;
             } else {
                 const int extra = -ax - 1; // workers that arrived after the one that created the node
@@ -1609,14 +1639,16 @@ __device__ __forceinline__ void wchunk_store(const AzParams &P, int tree, int c,
     if (lane < 8 * min(8, nw - c)) base[lane] = wr;
 }
 __device__ __forceinline__ void workers_select_phase(const AzParams &P, int tree, int nw, int lane, WHdr &h, float *d_boards,
-                                                     int *d_leaf_kind, unsigned *d_expand_mask, unsigned *d_clear_mask)
+                                                     int *d_leaf_kind, unsigned *d_expand_mask, unsigned *d_clear_mask STAMP_PARAM)
 {
     WState rs;
     load_state_hdr<EPL>(P, tree, lane, h.words, rs);
     for (int c = 0; c < nw; c += 8) {
         int wr = wchunk_load(P, tree, c, nw, lane);
-        for (int wi = 0; wi < min(8, nw - c); wi++)
-            wselect_body(P, tree, c + wi, wi, nw, lane, rs, h, wr, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
+        for (int wi = 0; wi < min(8, nw - c); wi++) {
+            wselect_body(P, tree, c + wi, wi, nw, lane, rs, h, wr, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask STAMP_ARG);
+            STAMP(7);
+        }
         wchunk_store(P, tree, c, nw, lane, wr);
     }
 }
@@ -1635,15 +1667,16 @@ __global__ __launch_bounds__(64) void k_workers_select(AzParams P, int nw, float
 {
     const int tree = blockIdx.x + P.tree_base, lane = threadIdx.x;
     WHdr h;
-    whdr_load(&P.trees[tree], lane, h);
-    workers_select_phase(P, tree, nw, lane, h, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
+    STAMP_DECL;
+    whdr_load(P, tree, lane, h);
+    workers_select_phase(P, tree, nw, lane, h, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask STAMP_ARG);
     whdr_store(&P.trees[tree], lane, h);
 }
 __global__ __launch_bounds__(64) void k_workers_backup(AzParams P, int nw, const float *d_value, const float *d_prior, int prior_is_log)
 {
     const int tree = blockIdx.x + P.tree_base, lane = threadIdx.x;
     WHdr h;
-    whdr_load(&P.trees[tree], lane, h);
+    whdr_load(P, tree, lane, h);
     workers_backup_phase(P, tree, nw, lane, h, d_value, d_prior, prior_is_log);
     whdr_store(&P.trees[tree], lane, h);
 }
@@ -1653,10 +1686,15 @@ __global__ __launch_bounds__(64) void k_workers_backup_select(AzParams P, int nw
 {
     const int tree = blockIdx.x + P.tree_base, lane = threadIdx.x;
     WHdr h;
-    whdr_load(&P.trees[tree], lane, h);
+    STAMP_DECL;
+    whdr_load(P, tree, lane, h);
+    STAMP(0);
     workers_backup_phase(P, tree, nw, lane, h, d_value, d_prior, prior_is_log);
-    workers_select_phase(P, tree, nw, lane, h, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask);
+    STAMP(1);
+    workers_select_phase(P, tree, nw, lane, h, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask STAMP_ARG);
     whdr_store(&P.trees[tree], lane, h);
+    STAMP(2);
+    STAMP_ADD(tree);
 }
 
 // ------------------------------------------- network search in one launch (few trees)

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("AZ_LIBAZMCTS") or os.path.join(_HERE, "libazmcts.so")
 
 EVAL_UNIFORM, EVAL_HASH = 0, 1
 WORKERS_SEQUENTIAL, WORKERS_CONCURRENT = 0, 1
+MAX_WORKERS = 64  # AZ_MAX_WORKERS: concurrent workers per tree
 LEAF_NONE, LEAF_EXPAND, LEAF_TERMINAL = 0, 1, 2
 
 ERR_INVALID_MOVE, ERR_BAD_SIMS, ERR_NOT_DIST, ERR_EPS_RANGE, ERR_BAD_XY = 1, 2, 3, 4, 5

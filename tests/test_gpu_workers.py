@@ -38,7 +38,10 @@ def _compare(batch, trees, paths=((),)):
 
 
 @pytest.mark.parametrize("S,T,sims", [(9, 2, 31), (9, 4, 50), (9, 8, 3), (15, 4, 100), (15, 8, 40), (15, 2, 64),
-                                      (20, 4, 60), (20, 8, 33), (20, 2, 25)])
+                                      (20, 4, 60), (20, 8, 33), (20, 2, 25),
+                                      # the most workers the engine takes, a count that ends inside a chunk of eight, and
+                                      # more workers than the board has cells (terminal leaves, crowds in one new node)
+                                      (9, 64, 200), (7, 17, 60), (5, 64, 130), (15, 64, 64), (20, 33, 70)])
 @pytest.mark.parametrize("eps", [0.0, 0.25])
 def test_concurrent_workers_match_the_oracle_lockstep(S, T, sims, eps):
     from alphazero_amd import selfplay as sp
@@ -292,3 +295,15 @@ def test_concurrent_workers_at_full_width_against_the_oracle_on_sampled_trees(S,
     assert st["sims"] == G * plies * sims and st["sims"] * 0.9 < st["expansions"] + st["terminals"] <= st["sims"]
     assert np.all(batch.eng.get_errors() == 0)
     batch.close()
+
+
+def test_more_workers_than_the_engine_takes_are_refused():
+    from alphazero_amd import engine as E
+
+    e = E.Engine(2, 9, nodes_per_tree=64, cpuct=4.0)
+    e.set_threads(E.MAX_WORKERS)
+    with pytest.raises(E.EngineError) as ei:
+        e.set_threads(E.MAX_WORKERS + 1)
+    assert ei.value.code == E.ERR_ARG and "at most 64" in str(ei.value)
+    assert e.get_threads() == E.MAX_WORKERS  # the refused call changed nothing
+    e.close()

@@ -307,3 +307,38 @@ def test_more_workers_than_the_engine_takes_are_refused():
     assert ei.value.code == E.ERR_ARG and "at most 64" in str(ei.value)
     assert e.get_threads() == E.MAX_WORKERS  # the refused call changed nothing
     e.close()
+
+
+def test_pool_exhaustion_under_concurrent_workers_stops_the_tree_until_it_is_cleared():
+    """A worker that finds the node pool empty raises the tree's error: the workers after it in the step do
+    nothing, later steps skip the tree, the other trees of the batch go on, and a cleared tree searches again
+    and matches the oracle."""
+    from alphazero_amd import engine as E
+    from alphazero_amd import selfplay as sp
+
+    S, T, B = 9, 4, 3
+    batch = sp.TreeBatch(B, S, ExactTorchEvaluator(), cpuct=4.0, eps=0.0, threads=T, nodes_per_tree=24)
+    eng = batch.eng
+    with pytest.raises(RuntimeError, match=r"node pool exhausted \(tree 0; 3 trees in error\)"):  # (TreeBatch raises as the facade does)
+        batch.simulate(80)
+    assert list(eng.get_errors()) == [E.ERR_POOL_FULL] * B
+    counts0, root_n0 = eng.get_counts()
+    assert 0 < root_n0.min() and root_n0.max() < 80  # stopped half way
+    with pytest.raises(RuntimeError, match="node pool exhausted"):  # still pending: the trees are skipped
+        batch.simulate(8)
+    counts1, root_n1 = eng.get_counts()
+    assert np.array_equal(counts0, counts1) and np.array_equal(root_n0, root_n1)
+    eng.clear(1)
+    assert list(eng.get_errors()) == [E.ERR_POOL_FULL, 0, E.ERR_POOL_FULL]
+    with pytest.raises(RuntimeError, match=r"2 trees in error"):
+        batch.simulate(8)
+    ot = _oracle(S, T, 0.0)
+    ot.simulate(8, oracle_exact_evaluator(S))
+    counts, root_n = eng.get_counts()
+    assert root_n[1] == ot.root_n() and np.array_equal(counts[1].astype(np.int64), ot.root_counts())
+    assert root_n[0] == root_n0[0] and root_n[2] == root_n0[2]
+    eng.clear()
+    assert not eng.get_errors().any()
+    batch.simulate(8)
+    assert list(eng.get_counts()[1]) == [ot.root_n()] * B
+    batch.close()

@@ -51,9 +51,10 @@ def main():
             finally:
                 lib.az_net_set_form(0)
             n_net += 1
-        if n_fused % 24 == 0:
-            TW.test_concurrent_workers_match_the_oracle_lockstep(int(rng.choice([7, 9, 13, 15, 20])), int(rng.integers(2, 9)),
-                                                                 int(rng.integers(3, 90)), float(rng.choice([0.0, 0.25])))
+        if n_fused % 12 == 0:
+            T = int(rng.choice([int(rng.integers(2, 9)), int(rng.integers(9, 65))], p=[0.7, 0.3]))
+            TW.test_concurrent_workers_match_the_oracle_lockstep(int(rng.choice([5, 7, 9, 13, 15, 20])), T,
+                                                                 int(rng.integers(3, 90 if T <= 8 else 260)), float(rng.choice([0.0, 0.25])))
             n_workers += 1
         if n_fused % 48 == 0:
             TR.test_resident_self_play_equals_stream_driver(float(rng.choice([0.0, 0.25])), int(rng.integers(-1, 6)),

@@ -71,6 +71,7 @@ struct az_engine {
     double alpha = 1.0;
     int threads = 0;
     int schedule = AZ_WORKERS_CONCURRENT; // how az_simulate_net runs the workers of threads > 1
+    int net_path = AZ_NET_PATH_NONE;      // the launch sequence of the last network search
     int cuda = 0;
     unsigned long long device_bytes = 0;
     // device scratch
@@ -202,8 +203,9 @@ const char *kernel_err_text(int code)
     case AZ_ERR_NOISE_ROWS: return "noise table exhausted";
     case AZ_ERR_INVALID_MOVE: return "Invalid move";
     case AZ_ERR_NOT_DIST: return "Not a distribution";
-    case AZ_ERR_STATE: return "the tree's state does not allow this call (a record row outside the staging rows, or az_simulate_fused "
-                              "on a tree whose nodes carry visit deficits from concurrent workers)";
+    case AZ_ERR_STATE: return "the tree's state does not allow this call (a record row outside the staging rows, az_simulate_fused "
+                              "on a tree whose nodes carry visit deficits from concurrent workers, or a one-launch search with "
+                              "concurrent workers that was abandoned because a workgroup of its cluster never answered)";
     default: return "kernel error";
     }
 }
@@ -417,6 +419,7 @@ int az_set_schedule(az_engine *e, int schedule)
     return AZ_OK;
 }
 int az_get_schedule(const az_engine *e) { return e ? e->schedule : 0; }
+int az_get_net_path(const az_engine *e) { return e ? e->net_path : AZ_NET_PATH_NONE; }
 int az_get_threads(const az_engine *e) { return e->threads; }
 int az_set_cuda(az_engine *e, int cuda)
 {
@@ -651,7 +654,7 @@ int az_expand_backup(az_engine *e, const float *d_value, const float *d_prior, i
 // [n][size], values float [n], leaf codes int [n], two bit masks of the trees whose
 // leaf is to be expanded (steps alternate between them); every section 256-byte aligned.
 struct StageLayout {
-    size_t boards, logp, value, kinds, mask[2], mask_bytes, bytes;
+    size_t boards, logp, value, kinds, mask[2], mask_bytes, flags, flag_bytes, bytes;
 };
 static StageLayout stage_layout(int n, int size)
 {
@@ -664,7 +667,10 @@ static StageLayout stage_layout(int n, int size)
     L.mask_bytes = up((size_t)((n + 31) / 32) * AZ_MASK_STRIDE * sizeof(unsigned));
     L.mask[0] = L.kinds + up((size_t)n * sizeof(int));
     L.mask[1] = L.mask[0] + L.mask_bytes;
-    L.bytes = L.mask[1] + L.mask_bytes;
+    // the counters of the one-launch search with concurrent workers (two per position and one more), few positions only
+    L.flag_bytes = n <= 1024 ? up(AZ_CLUSTER_FLAG_INTS(n) * sizeof(int)) : 0;
+    L.flags = L.mask[1] + L.mask_bytes;
+    L.bytes = L.flags + L.flag_bytes;
     return L;
 }
 
@@ -712,7 +718,7 @@ static int net_groups(az_engine *e, int width, void *stream, NetGroup (&g)[AZ_MA
 // Cmcts::simulate with the network evaluated by az_net_eval: every search step is two launches per tree group
 // (network; backup + next select), the host never waits.
 static int simulate_net_steps(az_engine *e, int n, const float *d_params, int front, int pol, int val, char *stage,
-                              void *stream)
+                              void *stream, bool one_launch_workers)
 {
     // thread fan-out of cmcts.cpp:98-119: th_num workers of `per` searches
     int th_num = 1, per = n;
@@ -740,16 +746,30 @@ static int simulate_net_steps(az_engine *e, int n, const float *d_params, int fr
         if (e->n_trees <= cus && az_net_get_form() == AZ_NET_FORM_AUTO && !(sw && atoi(sw) == 0)) {
             if (e->ops->net_search(e->P, th_num, per, d_params, front, pol, val, stream))
                 return fail(AZ_ERR_HIP, "net_search launch failed");
+            e->net_path = AZ_NET_PATH_ONE_LAUNCH;
             return AZ_OK;
         }
     }
     if (concurrent)
         if (int rc = check_workers(e, th_num)) return rc;
-    HIP_TRY(hipMemsetAsync(stage + L.mask[0], 0, 2 * L.mask_bytes, (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(stage + L.mask[0], 0, 2 * L.mask_bytes + L.flag_bytes, (hipStream_t)stream));
     if (concurrent) // every worker builds a generator of its own (cmcts.cpp:132-133)
         HIP_TRY(hipMemset2DAsync((char *)e->P.workers + offsetof(AzWorker, noise_row), sizeof(AzWorker), 0, sizeof(int),
                                  (size_t)e->n_trees * e->P.max_workers, (hipStream_t)stream));
+    // Concurrent workers, and every tree can have th_num + 1 CUs to itself: the whole call is one launch here too
+    // (k_net_search_workers; same arithmetic, same switches as above).  Not from the allocation-free entry point, whose
+    // callers may be capturing the stream (a cooperative launch cannot be captured).
+    if (concurrent && one_launch_workers && L.flag_bytes != 0) {
+        const char *sw = getenv("AZ_NET_SEARCH");
+        if (az_net_get_form() == AZ_NET_FORM_AUTO && !(sw && atoi(sw) == 0)) {
+            const int rc = e->ops->net_search_workers(e->P, th_num, per, d_params, front, pol, val, kinds, value, logp,
+                                                      reinterpret_cast<int *>(stage + L.flags), stream);
+            if (rc == 0) { e->net_path = AZ_NET_PATH_CLUSTER; return AZ_OK; }
+            if (rc == 1) return fail(AZ_ERR_HIP, "net_search_workers launch failed");
+        }
+    }
 
+    e->net_path = AZ_NET_PATH_STEPPED;
     NetGroup groups[AZ_MAX_GROUPS];
     const int ng = net_groups(e, width, stream, groups);
     if (ng > 1) { // the groups' streams start behind everything queued on the caller's stream so far
@@ -843,7 +863,7 @@ int az_simulate_net(az_engine *e, int n, const float *d_params, int front_layers
         e->stage_bytes = L.bytes;
         e->device_bytes += L.bytes;
     }
-    const int rc = simulate_net_steps(e, n, d_params, front_layers, policy_layers, value_layers, e->d_stage, stream);
+    const int rc = simulate_net_steps(e, n, d_params, front_layers, policy_layers, value_layers, e->d_stage, stream, true);
     note_queued(e, stream);
     return rc;
 }
@@ -869,7 +889,7 @@ int az_simulate_net_noalloc(az_engine *e, int n, const float *d_params, int fron
     DeviceGuard g(e->device);
     char *ptr = g_scratch_ptr[e->device]; // resolved by az_create on this device
     if (!ptr) return fail(AZ_ERR_STATE, "the fixed staging buffer was not resolved on device %d", e->device);
-    const int rc = simulate_net_steps(e, n, d_params, front_layers, policy_layers, value_layers, ptr, stream);
+    const int rc = simulate_net_steps(e, n, d_params, front_layers, policy_layers, value_layers, ptr, stream, false);
     note_queued(e, stream);
     return rc;
 }

@@ -1407,7 +1407,18 @@ enum { WF_KIND = 0, WF_PATH_LEN = 1, WF_VALUE = 2, WF_NOISE_ROW = 3, WF_LEAF_SLO
 __device__ __forceinline__ int wget(int wr, int wi, int field) { return __builtin_amdgcn_readlane(wr, wi * 8 + field); }
 __device__ __forceinline__ void wput(int &wr, int lane, int wi, int field, int v) { wr = lane == wi * 8 + field ? v : wr; }
 
+// Accesses that are coherent between the XCDs of the device without a cache write-back or invalidate: relaxed atomics
+// at agent scope go through to memory (COH = true below: the exchange of the one-launch cluster search, where the
+// master keeps its tree in its L2 for the whole call and an acquire would drop it at every step).
+__device__ __forceinline__ void coh_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int coh_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float coh_load_f(const float *p) { return __int_as_float(coh_load(reinterpret_cast<const int *>(p))); }
+// every store of this wavefront so far has arrived before anything after this line is issued
+__device__ __forceinline__ void coh_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // worker (chunk position wi, index w) descends to its leaf
+// COH: the leaf goes out as the position's 64 bit rows (d_boards is then int [positions][64]) through coherent stores
+template <bool COH = false>
 __device__ __forceinline__ void wselect_body(const AzParams &P, int tree, int w, int wi, int nw, int lane, const WState &root_state,
                                              WHdr &h, int &wr, float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask,
                                              unsigned *d_clear_mask STAMP_PARAM)
@@ -1496,7 +1507,10 @@ __device__ __forceinline__ void wselect_body(const AzParams &P, int tree, int w,
         nn = pk.n - 1 - ax;
     }
     if (err) { kind = AZ_LEAF_NONE; h.err = err; }
-    if (kind == AZ_LEAF_EXPAND) write_board(s, d_boards + (size_t)out * 2 * SIZE, lane);
+    if (kind == AZ_LEAF_EXPAND) {
+        if (COH) coh_store(reinterpret_cast<int *>(d_boards) + (size_t)out * 64 + lane, (int)s.rb);
+        else write_board(s, d_boards + (size_t)out * 2 * SIZE, lane);
+    }
     wput(wr, lane, wi, WF_KIND, kind);
     wput(wr, lane, wi, WF_PATH_LEN, depth);
     wput(wr, lane, wi, WF_VALUE, __float_as_int(leaf_value));
@@ -1508,6 +1522,8 @@ __device__ __forceinline__ void wselect_body(const AzParams &P, int tree, int w,
 }
 
 // worker (chunk position wi, index w) finishes its search: set_prior + backup
+// COH: the value and the priors are read through coherent loads
+template <bool COH = false>
 __device__ __forceinline__ void wbackup_body(const AzParams &P, int tree, int w, int wi, int nw, int lane, WHdr &h, int &wr,
                                              const float *d_value, const float *d_prior, int prior_is_log)
 {
@@ -1543,12 +1559,12 @@ __device__ __forceinline__ void wbackup_body(const AzParams &P, int tree, int w,
         const int noise_row = wget(wr, wi, WF_NOISE_ROW);
         // requested before it is known whether this worker expands: the node's mark, the value, the priors, the noise
         int ax = is_root ? 0 : P.aux[tbase + leaf_slot];
-        const float v_in = d_value[out];
+        const float v_in = COH ? coh_load_f(d_value + out) : d_value[out];
         float pr[E];
 #pragma unroll
         for (int k = 0; k < E; k++) {
             const int a = lane * E + k;
-            pr[k] = a < SIZE ? d_prior[(size_t)out * SIZE + a] : 0.f;
+            pr[k] = a < SIZE ? (COH ? coh_load_f(d_prior + (size_t)out * SIZE + a) : d_prior[(size_t)out * SIZE + a]) : 0.f;
         }
         double nz[E];
 #pragma unroll
@@ -1705,7 +1721,7 @@ __global__ __launch_bounds__(64) void k_workers_backup_select(AzParams P, int nw
 // (aznet::team_position, the code of k_net_eval); the leaf's planes, its code, the value and the log-priors
 // pass through LDS.  Same arithmetic as the launches it replaces, hence the same results.
 using NetG = aznet::Geo<S, 8>;
-constexpr int NET_SEARCH_LDS_FLOATS = 2 * NetG::BUF + 16 + NetG::SIZE + 2 * NetG::SIZE + NetG::SIZE + 16;
+constexpr int NET_SEARCH_LDS_FLOATS = 2 * NetG::BUF + 16 + NetG::SIZE + 2 * NetG::SIZE + NetG::SIZE + 16 + 64; // (+ 64: the cluster search's bit rows)
 __global__ __launch_bounds__(NetG::NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_search(
     AzParams P, int th_num, int per, const float *prm, int front, int pol, int val)
 {
@@ -1744,6 +1760,124 @@ __global__ __launch_bounds__(NetG::NTHR) __attribute__((amdgpu_waves_per_eu(2, 2
             }
             if (wave == 0) expand_backup_body(P, tree, 0, lane, value, logp, 1);
             // (wavefront 0 goes on to the next select; the others wait for it at the barrier above)
+        }
+    }
+}
+
+// ----------------------- network search in one launch, concurrent workers (few trees)
+// The lock-step schedule of k_workers_* / az_net_eval for batches small enough that every tree gets nw + 1 CUs of
+// its own: ONE launch for all steps of a call.  Workgroup 0 of a tree's cluster is the master (its wavefront 0 runs
+// the workers' descents and backups, the code of the stepped kernels); workgroup 1 + w is an eight-wavefront
+// evaluator team for worker w's leaf (aznet::team_position, the code of k_net_eval).  Hence the same results as the
+// stepped launches, which the tests require bit for bit.  What the launch saves: two dispatches per step, and the
+// workers' leaves no longer wait for each other -- worker w's position is evaluated while the master still descends
+// for worker w + 1, and its backup runs while later positions are still being evaluated.
+// The workgroups of a cluster run on different CUs (and XCDs, whose L2 caches are not coherent with each other) and
+// talk through device memory: per position a counter `go` (master -> team: 4 * (s + 1) + the leaf's AZ_LEAF_* code
+// once leaf w of step s is in place) and a counter `done` (team -> master: s + 1 once its value and log-priors are
+// in place).  Everything exchanged -- the counters, the leaf (its 64 bit rows, not 2 * SIZE floats), the value and the
+// log-priors -- is written and read with relaxed atomics at agent scope, which go through to memory; the producer
+// waits for its stores to arrive before it raises the counter.  No cache is written back or invalidated, so the
+// master's tree stays in its L2 for the whole call.  The master waits for a team only when the leaf is to be
+// evaluated, so a team can find `go` several steps ahead: those steps had nothing for it, and it skips them.
+// Every workgroup of the grid must be resident for the waits to end: the launcher asks for a cooperative launch, which
+// guarantees it or fails.  Every wait is bounded all the same: a wait that runs out raises `stop`, which ends every
+// other wait of the launch at once, and the tree reports AZ_ERR_STATE.
+// the counter's value once it has reached `want`, -1 when the launch is being abandoned
+__device__ __forceinline__ int cluster_wait(const int *flag, int want, int *stop)
+{
+    for (int it = 0; it < (1 << 22); it++) {
+        const int v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v >= want) {
+            asm volatile("" ::: "memory"); // (the compiler keeps the reads of what the counter announces behind this one)
+            return v;
+        }
+        if ((it & 31) == 31 && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return -1;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __hip_atomic_store(stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return -1;
+}
+__global__ __launch_bounds__(NetG::NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_search_workers(
+    AzParams P, int nw, int per, const float *prm, int front, int pol, int val, int *d_leaf_kind, float *d_value, float *d_logp,
+    int *d_flags)
+{
+    using G = NetG;
+    extern __shared__ float lds[];
+    const int cluster = nw + 1;
+    const int tree = (int)(blockIdx.x / cluster), role = (int)(blockIdx.x % cluster);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = uni(tid >> 6);
+    const int n_pos = (int)(gridDim.x / cluster) * nw;
+    int *go = d_flags, *done = d_flags + n_pos, *stop = d_flags + 2 * n_pos;
+    int *rows_x = d_flags + 2 * n_pos + 64; // [n_pos][64] the leaves' bit rows
+    if (role == 0) { // ---- the master: the worker kernels' code, all steps
+        if (tid >= 64) return;
+        WHdr h;
+        STAMP_DECL;
+        whdr_load(P, tree, lane, h);
+        WState rs;
+        load_state_hdr<EPL>(P, tree, lane, h.words, rs);
+        int wr = wchunk_load(P, tree, 0, nw, lane);
+        for (int step = 0; step < per; step++) {
+            for (int wi = 0; wi < nw; wi++) {
+                wselect_body<true>(P, tree, wi, wi, nw, lane, rs, h, wr, reinterpret_cast<float *>(rows_x), d_leaf_kind, nullptr,
+                                   nullptr STAMP_ARG);
+                // (every step and worker, whatever the leaf: the team counts its steps by these)
+                coh_stores_done();
+                if (lane == 0) coh_store(&go[tree * nw + wi], 4 * (step + 1) + wget(wr, wi, WF_KIND));
+            }
+            for (int wi = 0; wi < nw; wi++) {
+                if (wget(wr, wi, WF_KIND) == AZ_LEAF_EXPAND && cluster_wait(&done[tree * nw + wi], step + 1, stop) < 0) {
+                    h.err = AZ_ERR_STATE;
+                    wput(wr, lane, wi, WF_KIND, AZ_LEAF_NONE);
+                }
+                wbackup_body<true>(P, tree, wi, wi, nw, lane, h, wr, d_value, d_logp, 1);
+            }
+        }
+        wchunk_store(P, tree, 0, nw, lane, wr);
+        whdr_store(&P.trees[tree], lane, h);
+        return;
+    }
+    // ---- an evaluator team: worker `role - 1` of this tree
+    float *F = lds, *W = lds + G::BUF;
+    float *red = lds + 2 * G::BUF;                       // [16] reductions of the heads
+    float *logit = red + 16;                             // [SIZE]
+    float *planes = logit + G::SIZE;                     // [2][SIZE] the leaf
+    float *logp = planes + 2 * G::SIZE;                  // [SIZE]
+    float *value = logp + G::SIZE;                       // [1]
+    int *code = reinterpret_cast<int *>(value + 1);      // [2] what `go` held, steps alternate between the cells
+    int *rows = code + 2;                                // [64] the leaf's bit rows
+    const int out = tree * nw + role - 1;
+    for (int i = tid; i < 2 * G::BUF; i += G::NTHR) lds[i] = 0.f; // halos stay zero from here on
+    aznet::TeamCtx<G> ctx;
+    aznet::team_setup<G>(ctx, prm, front, pol, val, wave, lane);
+    __syncthreads();
+    for (int step = 0; step < per; step++) {
+        // (a wavefront that has not read the step's code yet when thread 0 is already waiting for the next step finds
+        // it untouched in the cell of its parity; by the time the cell is written again every wavefront has passed
+        // the barrier of the step in between)
+        int *cd = code + (step & 1);
+        if (tid == 0) cd[0] = cluster_wait(&go[out], 4 * (step + 1), stop);
+        __syncthreads();
+        const int gv = cd[0];
+        if (gv < 0) break; // (workgroup-uniform)
+        if ((gv >> 2) == step + 1 && (gv & 3) == AZ_LEAF_EXPAND) {
+            if (tid < 64) rows[tid] = coh_load(rows_x + (size_t)out * 64 + tid);
+            __syncthreads();
+            for (int i = tid; i < 2 * G::SIZE; i += G::NTHR) { // the planes as select writes them (write_board)
+                const int plane = i / G::SIZE, p = i - plane * G::SIZE;
+                planes[i] = (float)(((unsigned)rows[plane * 32 + p / S] >> (p % S)) & 1u);
+            }
+            __syncthreads();
+            aznet::team_position<G>(ctx, F, W, red, logit, planes, value, logp, tid, wave, lane);
+            __syncthreads();
+            for (int i = tid; i < G::SIZE; i += G::NTHR)
+                coh_store(reinterpret_cast<int *>(d_logp) + (size_t)out * G::SIZE + i, __float_as_int(logp[i]));
+            if (tid == 0) coh_store(reinterpret_cast<int *>(d_value) + out, __float_as_int(value[0]));
+            coh_stores_done(); // this wavefront's outputs have arrived ...
+            __syncthreads();   // ... and so have everyone's
+            if (tid == 0) coh_store(&done[out], step + 1);
         }
     }
 }
@@ -2255,6 +2389,38 @@ int l_net_search(const AzParams &P, int th_num, int per, const float *d_params, 
                        front, pol, val);
     return launch_status();
 }
+// returns 0 when launched, 1 when a launch was tried and failed, 2 when this device cannot hold the grid at once
+// (the caller then takes the stepped launches)
+int l_net_search_workers(const AzParams &P, int nw, int per, const float *d_params, int front, int pol, int val, int *d_leaf_kind,
+                         float *d_value, float *d_logp, int *d_flags, void *stream)
+{
+    const size_t lds_bytes = (size_t)NET_SEARCH_LDS_FLOATS * sizeof(float);
+    static int blocks_per_cu[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 2;
+    if (blocks_per_cu[dev] == 0) {
+        if (hipFuncSetAttribute((const void *)k_net_search_workers, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) !=
+            hipSuccess)
+            return 2;
+        int coop = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_net_search_workers, NetG::NTHR, lds_bytes) != hipSuccess)
+            per_cu = -1;
+        blocks_per_cu[dev] = per_cu > 0 ? per_cu : -1;
+    }
+    int cus = 0;
+    if (blocks_per_cu[dev] < 0 || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 2;
+    const int grid = P.n_trees * (nw + 1);
+    if (nw > 8 || grid > cus) return 2; // (one workgroup per CU: a team then has its CU's matrix cores to itself)
+    AzParams Pv = P;
+    void *args[] = {&Pv, &nw, &per, &d_params, &front, &pol, &val, &d_leaf_kind, &d_value, &d_logp, &d_flags};
+    if (hipLaunchCooperativeKernel((const void *)k_net_search_workers, dim3(grid), dim3(NetG::NTHR), args, (unsigned)lds_bytes,
+                                   (hipStream_t)stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return 2;
+    }
+    return launch_status();
+}
 int l_expand_backup(const AzParams &P, const float *d_value, const float *d_prior, int is_log, void *stream)
 {
     hipLaunchKernelGGL(k_expand_backup, dim3(P.n_trees), dim3(64), 0, (hipStream_t)stream, P, d_value, d_prior,
@@ -2319,6 +2485,7 @@ extern "C" const AzShapeOps *AZ_CAT(az_shape_ops_, AZ_S)(void)
     static const AzShapeOps ops = {
         AZ_S, SP, l_simulate_fused, l_select, l_expand_backup, l_backup_select, l_net_search, l_make_move, l_clear, l_select_greedy, l_get_counts,
         l_choose_moves, l_dirichlet, l_restart, l_workers_select, l_workers_backup, l_workers_backup_select, l_choose_moves_staged,
+        l_net_search_workers,
     };
     return &ops;
 }

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("AZ_LIBAZMCTS") or os.path.join(_HERE, "libazmcts.so")
 EVAL_UNIFORM, EVAL_HASH = 0, 1
 WORKERS_SEQUENTIAL, WORKERS_CONCURRENT = 0, 1
 MAX_WORKERS = 64  # AZ_MAX_WORKERS: concurrent workers per tree
+NET_PATH_NONE, NET_PATH_STEPPED, NET_PATH_ONE_LAUNCH, NET_PATH_CLUSTER = 0, 1, 2, 3
 LEAF_NONE, LEAF_EXPAND, LEAF_TERMINAL = 0, 1, 2
 
 ERR_INVALID_MOVE, ERR_BAD_SIMS, ERR_NOT_DIST, ERR_EPS_RANGE, ERR_BAD_XY = 1, 2, 3, 4, 5
@@ -45,6 +46,7 @@ SYMBOLS = [
     ("az_get_threads", _i, [_vp]),
     ("az_set_schedule", _i, [_vp, _i]),
     ("az_get_schedule", _i, [_vp]),
+    ("az_get_net_path", _i, [_vp]),
     ("az_select_workers", _i, [_vp, _i, _vp, _vp, _vp]),
     ("az_expand_backup_workers", _i, [_vp, _i, _vp, _vp, _i, _vp]),
     ("az_set_cuda", _i, [_vp, _i]),
@@ -197,6 +199,7 @@ class Engine:
     def get_threads(self): return self.L.az_get_threads(self.h)
     def set_schedule(self, v): self._check(self.L.az_set_schedule(self.h, int(v)))
     def get_schedule(self): return self.L.az_get_schedule(self.h)
+    def get_net_path(self): return self.L.az_get_net_path(self.h)
     def set_cuda(self, v): self._check(self.L.az_set_cuda(self.h, v))
     def get_cuda(self): return self.L.az_get_cuda(self.h)
     def device_bytes(self): return self.L.az_device_bytes(self.h)

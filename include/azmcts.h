@@ -199,12 +199,19 @@ int az_expand_backup_workers(az_engine *e, int n_workers, const float *d_value, 
  * return to the caller per search; threads > 1: the workers in lock step or one after
  * another, see az_set_schedule).  An
  * engine of at most one tree per CU runs the whole call as ONE launch (a workgroup
- * per tree selects, evaluates and backs up; same arithmetic, same results).
+ * per tree selects, evaluates and backs up; same arithmetic, same results), and so
+ * does an engine with concurrent workers (at most 8) whose every tree can have
+ * threads + 1 CUs to itself (a master workgroup and one evaluator team per worker).
+ * AZ_NET_SEARCH=0 in the environment keeps the stepped launches.
  * d_params / *_layers: as az_net_eval takes them.  The step's leaf boards, codes,
  * values and log-priors live in a buffer the engine allocates on first use.
  * Asynchronous; errors surface at az_sync_check. */
 int az_simulate_net(az_engine *e, int n, const float *d_params, int front_layers, int policy_layers,
                     int value_layers, void *stream);
+/* Which launch sequence the engine's last az_simulate_net / az_simulate_net_noalloc call took
+ * (diagnostics and tests; the results do not depend on it; no counterpart in the reference). */
+enum { AZ_NET_PATH_NONE = 0, AZ_NET_PATH_STEPPED = 1, AZ_NET_PATH_ONE_LAUNCH = 2, AZ_NET_PATH_CLUSTER = 3 };
+int az_get_net_path(const az_engine *e);
 /* az_simulate_net for callers that cannot allocate device memory (code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc): same
  * arguments, same kernels, same results, but the step staging lives in a fixed

@@ -342,3 +342,103 @@ def test_pool_exhaustion_under_concurrent_workers_stops_the_tree_until_it_is_cle
     batch.simulate(8)
     assert list(eng.get_counts()[1]) == [ot.root_n()] * B
     batch.close()
+
+
+def _net_engines(B, S, T, sims, plies, seed):
+    from alphazero_amd import engine as E
+
+    size = S * S
+    engs = []
+    for _ in range(2):
+        e = E.Engine(B, S, nodes_per_tree=(sims + 2 * T) * plies + 64, cpuct=4.0)
+        e.set_alpha_default()
+        e.set_eps(0.25)
+        e.set_threads(T)
+        e.set_noise_table(np.random.default_rng(seed).dirichlet(np.full(size, e.get_alpha()), size=sims + 2))
+        engs.append(e)
+    return engs
+
+
+@pytest.mark.parametrize("B,S,T,sims", [(1, 15, 4, 200), (1, 20, 8, 120), (28, 15, 8, 40), (51, 9, 4, 33), (3, 13, 2, 75),
+                                        (40, 6, 5, 50), (85, 5, 2, 30), (7, 19, 3, 2)])
+def test_one_launch_cluster_search_equals_the_stepped_launches(B, S, T, sims, monkeypatch):
+    """az_simulate_net with concurrent workers on a batch small enough for a cluster of T + 1 workgroups per tree
+    (k_net_search_workers: the master's descents and backups overlap with the evaluator teams) against the
+    stepped launches (AZ_NET_SEARCH=0): every statistic of every tree bit-identical, through re-rooting, with
+    idle trees, and on small boards to the end of the games (terminal leaves, which no team evaluates)."""
+    import torch
+    from alphazero_amd import engine as E
+    from test_gpu_configs import _fused
+
+    size, plies = S * S, (S * S - 6 if S <= 6 else 3)
+    _, ev = _fused(S, seed=11)
+    a, b = _net_engines(B, S, T, sims, plies, seed=B + S)
+    stream = torch.cuda.current_stream().cuda_stream
+    first = np.array([O.opening(size, 3 * g + 2)[0] for g in range(B)], np.int32)
+    active = (np.arange(B) % 5 != 3).astype(np.uint8) if B > 4 else None
+    for e in (a, b):
+        e.make_move(first)
+        e.set_active(active)
+    for ply in range(plies):
+        monkeypatch.delenv("AZ_NET_SEARCH", raising=False)
+        a.simulate_net(sims, ev.params.data_ptr(), ev.fused_layers, stream)
+        assert a.get_net_path() == E.NET_PATH_CLUSTER
+        monkeypatch.setenv("AZ_NET_SEARCH", "0")
+        b.simulate_net(sims, ev.params.data_ptr(), ev.fused_layers, stream)
+        assert b.get_net_path() == E.NET_PATH_STEPPED
+        ca, ra = a.get_counts()
+        cb, rb = b.get_counts()
+        assert np.array_equal(ra, rb) and np.array_equal(ca, cb), ply
+        assert a.get_stats() == b.get_stats()
+        _, _, winner = a.get_states()
+        live = [t for t in range(B) if winner[t] == -1 and (active is None or active[t])]
+        for t in live[:: max(1, len(live) // 5)]:
+            na, nb = a.get_node(t, []), b.get_node(t, [])
+            assert na[0] == nb[0] and np.array_equal(na[2], nb[2]) and np.array_equal(na[3], nb[3]), (ply, t)
+            best = int(ca[t].argmax())
+            na, nb = a.get_node(t, [best]), b.get_node(t, [best])
+            assert (na is None) == (nb is None)
+            if na is not None:
+                assert na[0] == nb[0] and np.array_equal(na[1], nb[1]) and np.array_equal(na[2], nb[2]), (ply, t)
+        act = ca.argmax(axis=1).astype(np.int32)
+        raw = a.get_raw_boards().reshape(B, 2, size).sum(axis=1)
+        empty = (raw == 0).argmax(axis=1).astype(np.int32)
+        act = np.where(ca.sum(axis=1) > 0, act, empty)
+        act[winner != -1] = -1  # finished games stay as they are
+        if active is not None:
+            act[active == 0] = -1
+        a.make_move(act)
+        b.make_move(act)
+    if S <= 6:
+        assert a.get_stats()["terminals"] > 0  # searches that ended on a finished game: leaves no team evaluates
+    a.close()
+    b.close()
+
+
+def test_one_launch_cluster_search_reports_pool_exhaustion_like_the_stepped_launches(monkeypatch):
+    import torch
+    from alphazero_amd import engine as E
+    from test_gpu_configs import _fused
+
+    S, T, B, sims = 9, 4, 3, 80
+    _, ev = _fused(S, seed=2)
+    stream = torch.cuda.current_stream().cuda_stream
+    got = []
+    for path in ("cluster", "stepped"):
+        if path == "stepped":
+            monkeypatch.setenv("AZ_NET_SEARCH", "0")
+        e = E.Engine(B, S, nodes_per_tree=24, cpuct=4.0)
+        e.set_eps(0.0)
+        e.set_threads(T)
+        with pytest.raises(E.EngineError, match=r"node pool exhausted \(tree 0; 3 trees in error\)") as ei:
+            e.simulate_net(sims, ev.params.data_ptr(), ev.fused_layers, stream)
+        assert ei.value.code == E.ERR_POOL_FULL
+        assert e.get_net_path() == (E.NET_PATH_CLUSTER if path == "cluster" else E.NET_PATH_STEPPED)
+        got.append((e.get_counts(), e.get_stats(), list(e.get_errors())))
+        e.clear()
+        e.simulate_net(8, ev.params.data_ptr(), ev.fused_layers, stream)
+        got[-1] += (e.get_counts(),)
+        e.close()
+    (c0, s0, e0, d0), (c1, s1, e1, d1) = got
+    assert np.array_equal(c0[0], c1[0]) and np.array_equal(c0[1], c1[1]) and s0 == s1 and e0 == e1
+    assert np.array_equal(d0[0], d1[0]) and np.array_equal(d0[1], d1[1])

@@ -106,9 +106,9 @@ struct AzFusedArgs {
     unsigned long long hash_seed;
 };
 
-// ints of the exchange area of net_search_workers for n positions: two counters per position, the stop word (padded
-// to 64), 64 bit rows per position
-#define AZ_CLUSTER_FLAG_INTS(n) (2 * (size_t)(n) + 64 + 64 * (size_t)(n))
+// ints of the exchange area of net_search_workers for n positions of `size` actions: the stop word (padded to 64
+// ints), then per position 64 tagged bit rows and size + 1 tagged result words, two ints each
+#define AZ_CLUSTER_FLAG_INTS(n, size) (64 + 2 * (size_t)(n) * (64 + (size_t)(size) + 1))
 
 // launchers exported by each per-shape translation unit (az_kernels.hip built
 // with -DAZ_S=<shape>); the engine picks the table entry of its shape.
@@ -150,12 +150,12 @@ struct AzShapeOps {
     int (*choose_moves_staged)(const AzParams &, const double *d_u, int *d_actions, float *d_stage, int max_plies,
                                const int *d_ply, void *stream);
     // the whole network search of a simulate call with nw concurrent workers per tree in one launch (a cluster of
-    // nw + 1 workgroups per tree, at most one workgroup per CU); staging arrays as the stepped launches use them,
-    // d_flags: AZ_CLUSTER_FLAG_INTS(n_trees * nw) ints, the first 2 * n_trees * nw + 1 of them zero.  0 = launched,
-    // 1 = the launch failed, 2 = not possible on this device or for this batch (nothing was launched: take the
-    // stepped launches)
+    // nw + 1 workgroups per tree, at most one workgroup per CU); d_leaf_kind as the stepped launches use it,
+    // d_flags: AZ_CLUSTER_FLAG_INTS(n_trees * nw, SIZE) zeroed ints, 256-byte aligned (the exchange area between the
+    // workgroups of a cluster).  0 = launched, 1 = the launch failed, 2 = not possible on this device or for this
+    // batch (nothing was launched: take the stepped launches)
     int (*net_search_workers)(const AzParams &, int nw, int per, const float *d_params, int front_layers, int policy_layers,
-                              int value_layers, int *d_leaf_kind, float *d_value, float *d_logp, int *d_flags, void *stream);
+                              int value_layers, int *d_leaf_kind, int *d_flags, void *stream);
 };
 
 // Words of the expand masks are AZ_MASK_STRIDE words apart: the trees' atomic ORs then spread over four times

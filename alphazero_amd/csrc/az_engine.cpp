@@ -667,8 +667,8 @@ static StageLayout stage_layout(int n, int size)
     L.mask_bytes = up((size_t)((n + 31) / 32) * AZ_MASK_STRIDE * sizeof(unsigned));
     L.mask[0] = L.kinds + up((size_t)n * sizeof(int));
     L.mask[1] = L.mask[0] + L.mask_bytes;
-    // the counters of the one-launch search with concurrent workers (two per position and one more), few positions only
-    L.flag_bytes = n <= 1024 ? up(AZ_CLUSTER_FLAG_INTS(n) * sizeof(int)) : 0;
+    // the exchange area of the one-launch search with concurrent workers (fewer positions than the device has CUs)
+    L.flag_bytes = n <= 512 ? up(AZ_CLUSTER_FLAG_INTS(n, size) * sizeof(int)) : 0;
     L.flags = L.mask[1] + L.mask_bytes;
     L.bytes = L.flags + L.flag_bytes;
     return L;
@@ -752,17 +752,20 @@ static int simulate_net_steps(az_engine *e, int n, const float *d_params, int fr
     }
     if (concurrent)
         if (int rc = check_workers(e, th_num)) return rc;
-    HIP_TRY(hipMemsetAsync(stage + L.mask[0], 0, 2 * L.mask_bytes + L.flag_bytes, (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(stage + L.mask[0], 0, 2 * L.mask_bytes, (hipStream_t)stream));
     if (concurrent) // every worker builds a generator of its own (cmcts.cpp:132-133)
         HIP_TRY(hipMemset2DAsync((char *)e->P.workers + offsetof(AzWorker, noise_row), sizeof(AzWorker), 0, sizeof(int),
                                  (size_t)e->n_trees * e->P.max_workers, (hipStream_t)stream));
     // Concurrent workers, and every tree can have th_num + 1 CUs to itself: the whole call is one launch here too
     // (k_net_search_workers; same arithmetic, same switches as above).  Not from the allocation-free entry point, whose
     // callers may be capturing the stream (a cooperative launch cannot be captured).
-    if (concurrent && one_launch_workers && L.flag_bytes != 0) {
+    if (concurrent && one_launch_workers && L.flag_bytes != 0 && th_num <= 8) {
+        int cus = 0;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device);
         const char *sw = getenv("AZ_NET_SEARCH");
-        if (az_net_get_form() == AZ_NET_FORM_AUTO && !(sw && atoi(sw) == 0)) {
-            const int rc = e->ops->net_search_workers(e->P, th_num, per, d_params, front, pol, val, kinds, value, logp,
+        if ((long long)e->n_trees * (th_num + 1) <= cus && az_net_get_form() == AZ_NET_FORM_AUTO && !(sw && atoi(sw) == 0)) {
+            HIP_TRY(hipMemsetAsync(stage + L.flags, 0, L.flag_bytes, (hipStream_t)stream)); // every tag: no step yet
+            const int rc = e->ops->net_search_workers(e->P, th_num, per, d_params, front, pol, val, kinds,
                                                       reinterpret_cast<int *>(stage + L.flags), stream);
             if (rc == 0) { e->net_path = AZ_NET_PATH_CLUSTER; return AZ_OK; }
             if (rc == 1) return fail(AZ_ERR_HIP, "net_search_workers launch failed");

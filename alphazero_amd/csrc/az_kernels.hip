@@ -1413,18 +1413,27 @@ __device__ __forceinline__ void wput(int &wr, int lane, int wi, int field, int v
 __device__ __forceinline__ void coh_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int coh_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float coh_load_f(const float *p) { return __int_as_float(coh_load(reinterpret_cast<const int *>(p))); }
-// every store of this wavefront so far has arrived before anything after this line is issued
-__device__ __forceinline__ void coh_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// a 32-bit payload with a 32-bit tag in ONE 64-bit access: whoever reads the tag it waits for has the payload too,
+// with no ordering between separate stores to arrange
+__device__ __forceinline__ void coh_store_tagged(unsigned long long *p, int tag, unsigned payload)
+{
+    __hip_atomic_store(p, ((unsigned long long)(unsigned)tag << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long coh_load_tagged(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // worker (chunk position wi, index w) descends to its leaf
-// COH: the leaf goes out as the position's 64 bit rows (d_boards is then int [positions][64]) through coherent stores
+// COH: the leaf is not written to d_boards: its 64 bit rows (this lane's one) are handed back in leaf_rb
 template <bool COH = false>
 __device__ __forceinline__ void wselect_body(const AzParams &P, int tree, int w, int wi, int nw, int lane, const WState &root_state,
                                              WHdr &h, int &wr, float *d_boards, int *d_leaf_kind, unsigned *d_expand_mask,
-                                             unsigned *d_clear_mask STAMP_PARAM)
+                                             unsigned *d_clear_mask, unsigned &leaf_rb STAMP_PARAM)
 {
     constexpr int E = EPL;
     const int out = tree * nw + w;
+    leaf_rb = 0u;
     if (d_clear_mask != nullptr && lane == 0 && (out & 31) == 0) d_clear_mask[(out >> 5) * AZ_MASK_STRIDE] = 0u;
     if (h.active == 0 || h.err != 0) { // (an error raised by an earlier worker of this step stops the others too)
         wput(wr, lane, wi, WF_KIND, AZ_LEAF_NONE);
@@ -1508,7 +1517,7 @@ __device__ __forceinline__ void wselect_body(const AzParams &P, int tree, int w,
     }
     if (err) { kind = AZ_LEAF_NONE; h.err = err; }
     if (kind == AZ_LEAF_EXPAND) {
-        if (COH) coh_store(reinterpret_cast<int *>(d_boards) + (size_t)out * 64 + lane, (int)s.rb);
+        if (COH) leaf_rb = s.rb;
         else write_board(s, d_boards + (size_t)out * 2 * SIZE, lane);
     }
     wput(wr, lane, wi, WF_KIND, kind);
@@ -1522,10 +1531,11 @@ __device__ __forceinline__ void wselect_body(const AzParams &P, int tree, int w,
 }
 
 // worker (chunk position wi, index w) finishes its search: set_prior + backup
-// COH: the value and the priors are read through coherent loads
+// COH: the value and the priors were read by the caller (v_pre, pr_pre); d_value / d_prior are not touched
 template <bool COH = false>
 __device__ __forceinline__ void wbackup_body(const AzParams &P, int tree, int w, int wi, int nw, int lane, WHdr &h, int &wr,
-                                             const float *d_value, const float *d_prior, int prior_is_log)
+                                             const float *d_value, const float *d_prior, int prior_is_log, float v_pre = 0.f,
+                                             const float *pr_pre = nullptr)
 {
     constexpr int E = EPL;
     const int kind = wget(wr, wi, WF_KIND);
@@ -1559,12 +1569,12 @@ __device__ __forceinline__ void wbackup_body(const AzParams &P, int tree, int w,
         const int noise_row = wget(wr, wi, WF_NOISE_ROW);
         // requested before it is known whether this worker expands: the node's mark, the value, the priors, the noise
         int ax = is_root ? 0 : P.aux[tbase + leaf_slot];
-        const float v_in = COH ? coh_load_f(d_value + out) : d_value[out];
+        const float v_in = COH ? v_pre : d_value[out];
         float pr[E];
 #pragma unroll
         for (int k = 0; k < E; k++) {
             const int a = lane * E + k;
-            pr[k] = a < SIZE ? (COH ? coh_load_f(d_prior + (size_t)out * SIZE + a) : d_prior[(size_t)out * SIZE + a]) : 0.f;
+            pr[k] = a < SIZE ? (COH ? pr_pre[k] : d_prior[(size_t)out * SIZE + a]) : 0.f;
         }
         double nz[E];
 #pragma unroll
@@ -1662,7 +1672,9 @@ __device__ __forceinline__ void workers_select_phase(const AzParams &P, int tree
     for (int c = 0; c < nw; c += 8) {
         int wr = wchunk_load(P, tree, c, nw, lane);
         for (int wi = 0; wi < min(8, nw - c); wi++) {
-            wselect_body(P, tree, c + wi, wi, nw, lane, rs, h, wr, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask STAMP_ARG);
+            unsigned unused_rb;
+            wselect_body(P, tree, c + wi, wi, nw, lane, rs, h, wr, d_boards, d_leaf_kind, d_expand_mask, d_clear_mask,
+                         unused_rb STAMP_ARG);
             STAMP(7);
         }
         wchunk_store(P, tree, c, nw, lane, wr);
@@ -1773,34 +1785,34 @@ __global__ __launch_bounds__(NetG::NTHR) __attribute__((amdgpu_waves_per_eu(2, 2
 // workers' leaves no longer wait for each other -- worker w's position is evaluated while the master still descends
 // for worker w + 1, and its backup runs while later positions are still being evaluated.
 // The workgroups of a cluster run on different CUs (and XCDs, whose L2 caches are not coherent with each other) and
-// talk through device memory: per position a counter `go` (master -> team: 4 * (s + 1) + the leaf's AZ_LEAF_* code
-// once leaf w of step s is in place) and a counter `done` (team -> master: s + 1 once its value and log-priors are
-// in place).  Everything exchanged -- the counters, the leaf (its 64 bit rows, not 2 * SIZE floats), the value and the
-// log-priors -- is written and read with relaxed atomics at agent scope, which go through to memory; the producer
-// waits for its stores to arrive before it raises the counter.  No cache is written back or invalidated, so the
-// master's tree stays in its L2 for the whole call.  The master waits for a team only when the leaf is to be
-// evaluated, so a team can find `go` several steps ahead: those steps had nothing for it, and it skips them.
+// talk through device memory with relaxed atomics at agent scope, which go through to memory: no cache is written
+// back or invalidated, so the master's tree stays in its L2 for the whole call.  Every word exchanged travels in a
+// 64-bit access together with a tag that names the step, so the reader that finds the tag it waits for has the word
+// as well and nobody waits for a store to arrive before raising a flag:
+//   leaf    [position][64]       master -> team: tag 4 * (step + 1) + the leaf's AZ_LEAF_* code, payload one bit row;
+//                                written at every step whatever the code (the team counts its steps by the tags)
+//   result  [position][SIZE + 1] team -> master: tag step + 1, payload a log-prior (SIZE of them) or the value
+// The master waits for a team only when the leaf is to be evaluated, so a team can find its tags several steps
+// ahead: those steps had nothing for it, and it skips them.
 // Every workgroup of the grid must be resident for the waits to end: the launcher asks for a cooperative launch, which
 // guarantees it or fails.  Every wait is bounded all the same: a wait that runs out raises `stop`, which ends every
 // other wait of the launch at once, and the tree reports AZ_ERR_STATE.
-// the counter's value once it has reached `want`, -1 when the launch is being abandoned
-__device__ __forceinline__ int cluster_wait(const int *flag, int want, int *stop)
+constexpr int CLUSTER_SPINS = 1 << 22;
+constexpr int CLUSTER_RESULT = SIZE + 1; // tagged words of a position's result
+// true while waiting may go on
+__device__ __forceinline__ bool cluster_keep_waiting(int &it, int *stop)
 {
-    for (int it = 0; it < (1 << 22); it++) {
-        const int v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v >= want) {
-            asm volatile("" ::: "memory"); // (the compiler keeps the reads of what the counter announces behind this one)
-            return v;
-        }
-        if ((it & 31) == 31 && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return -1;
-        __builtin_amdgcn_s_sleep(1);
+    it++;
+    if ((it & 31) == 0 && coh_load(stop) != 0) return false;
+    if (it >= CLUSTER_SPINS) {
+        coh_store(stop, 1);
+        return false;
     }
-    __hip_atomic_store(stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return -1;
+    __builtin_amdgcn_s_sleep(1);
+    return true;
 }
 __global__ __launch_bounds__(NetG::NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_search_workers(
-    AzParams P, int nw, int per, const float *prm, int front, int pol, int val, int *d_leaf_kind, float *d_value, float *d_logp,
-    int *d_flags)
+    AzParams P, int nw, int per, const float *prm, int front, int pol, int val, int *d_leaf_kind, int *d_flags)
 {
     using G = NetG;
     extern __shared__ float lds[];
@@ -1809,10 +1821,12 @@ __global__ __launch_bounds__(NetG::NTHR) __attribute__((amdgpu_waves_per_eu(2, 2
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = uni(tid >> 6);
     const int n_pos = (int)(gridDim.x / cluster) * nw;
-    int *go = d_flags, *done = d_flags + n_pos, *stop = d_flags + 2 * n_pos;
-    int *rows_x = d_flags + 2 * n_pos + 64; // [n_pos][64] the leaves' bit rows
+    int *stop = d_flags;
+    unsigned long long *leaf_x = reinterpret_cast<unsigned long long *>(d_flags + 64);
+    unsigned long long *result_x = leaf_x + (size_t)n_pos * 64;
     if (role == 0) { // ---- the master: the worker kernels' code, all steps
         if (tid >= 64) return;
+        constexpr int E = EPL;
         WHdr h;
         STAMP_DECL;
         whdr_load(P, tree, lane, h);
@@ -1821,18 +1835,42 @@ __global__ __launch_bounds__(NetG::NTHR) __attribute__((amdgpu_waves_per_eu(2, 2
         int wr = wchunk_load(P, tree, 0, nw, lane);
         for (int step = 0; step < per; step++) {
             for (int wi = 0; wi < nw; wi++) {
-                wselect_body<true>(P, tree, wi, wi, nw, lane, rs, h, wr, reinterpret_cast<float *>(rows_x), d_leaf_kind, nullptr,
-                                   nullptr STAMP_ARG);
-                // (every step and worker, whatever the leaf: the team counts its steps by these)
-                coh_stores_done();
-                if (lane == 0) coh_store(&go[tree * nw + wi], 4 * (step + 1) + wget(wr, wi, WF_KIND));
+                unsigned leaf_rb;
+                wselect_body<true>(P, tree, wi, wi, nw, lane, rs, h, wr, nullptr, d_leaf_kind, nullptr, nullptr, leaf_rb STAMP_ARG);
+                coh_store_tagged(leaf_x + (size_t)(tree * nw + wi) * 64 + lane, 4 * (step + 1) + wget(wr, wi, WF_KIND), leaf_rb);
             }
             for (int wi = 0; wi < nw; wi++) {
-                if (wget(wr, wi, WF_KIND) == AZ_LEAF_EXPAND && cluster_wait(&done[tree * nw + wi], step + 1, stop) < 0) {
-                    h.err = AZ_ERR_STATE;
-                    wput(wr, lane, wi, WF_KIND, AZ_LEAF_NONE);
+                float v_pre = 0.f, pr_pre[E];
+#pragma unroll
+                for (int k = 0; k < E; k++) pr_pre[k] = 0.f;
+                if (wget(wr, wi, WF_KIND) == AZ_LEAF_EXPAND) {
+                    // this lane's log-priors and the value, until every word carries this step's tag
+                    const unsigned long long *res = result_x + (size_t)(tree * nw + wi) * CLUSTER_RESULT;
+                    int it = 0;
+                    bool got = false;
+                    for (;;) {
+                        bool mine = true;
+#pragma unroll
+                        for (int k = 0; k < E; k++) {
+                            const int a = lane * E + k;
+                            if (a < SIZE) {
+                                const unsigned long long v = coh_load_tagged(res + a);
+                                mine = mine && (int)(v >> 32) == step + 1;
+                                pr_pre[k] = __int_as_float((int)(unsigned)v);
+                            }
+                        }
+                        const unsigned long long vv = coh_load_tagged(res + SIZE);
+                        mine = mine && (int)(vv >> 32) == step + 1;
+                        v_pre = __int_as_float((int)(unsigned)vv);
+                        if (__all(mine)) { got = true; break; }
+                        if (!cluster_keep_waiting(it, stop)) break;
+                    }
+                    if (!got) {
+                        h.err = AZ_ERR_STATE;
+                        wput(wr, lane, wi, WF_KIND, AZ_LEAF_NONE);
+                    }
                 }
-                wbackup_body<true>(P, tree, wi, wi, nw, lane, h, wr, d_value, d_logp, 1);
+                wbackup_body<true>(P, tree, wi, wi, nw, lane, h, wr, nullptr, nullptr, 1, v_pre, pr_pre);
             }
         }
         wchunk_store(P, tree, 0, nw, lane, wr);
@@ -1846,7 +1884,7 @@ __global__ __launch_bounds__(NetG::NTHR) __attribute__((amdgpu_waves_per_eu(2, 2
     float *planes = logit + G::SIZE;                     // [2][SIZE] the leaf
     float *logp = planes + 2 * G::SIZE;                  // [SIZE]
     float *value = logp + G::SIZE;                       // [1]
-    int *code = reinterpret_cast<int *>(value + 1);      // [2] what `go` held, steps alternate between the cells
+    int *code = reinterpret_cast<int *>(value + 1);      // [2] 1 evaluate / 0 nothing to do / -1 stop, steps alternate
     int *rows = code + 2;                                // [64] the leaf's bit rows
     const int out = tree * nw + role - 1;
     for (int i = tid; i < 2 * G::BUF; i += G::NTHR) lds[i] = 0.f; // halos stay zero from here on
@@ -1854,30 +1892,46 @@ __global__ __launch_bounds__(NetG::NTHR) __attribute__((amdgpu_waves_per_eu(2, 2
     aznet::team_setup<G>(ctx, prm, front, pol, val, wave, lane);
     __syncthreads();
     for (int step = 0; step < per; step++) {
-        // (a wavefront that has not read the step's code yet when thread 0 is already waiting for the next step finds
-        // it untouched in the cell of its parity; by the time the cell is written again every wavefront has passed
-        // the barrier of the step in between)
+        // (a wavefront that has not read the step's code yet when wavefront 0 is already waiting for the next step
+        // finds it untouched in the cell of its parity; by the time the cell is written again every wavefront has
+        // passed the barrier of the step in between)
         int *cd = code + (step & 1);
-        if (tid == 0) cd[0] = cluster_wait(&go[out], 4 * (step + 1), stop);
+        if (wave == 0) { // every lane waits for its own row
+            const unsigned long long *src = leaf_x + (size_t)out * 64 + lane;
+            unsigned long long v = 0ull;
+            int it = 0, verdict = -1;
+            for (;;) {
+                v = coh_load_tagged(src);
+                if (__all((int)(v >> 34) >= step + 1)) { // (tag >> 2 = the step the row belongs to, counted from 1)
+                    const int tag = (int)(v >> 32);
+                    verdict = __all((tag >> 2) == step + 1 && (tag & 3) == AZ_LEAF_EXPAND) ? 1 : 0;
+                    break;
+                }
+                if (!cluster_keep_waiting(it, stop)) break;
+            }
+            rows[lane] = (int)(unsigned)v;
+            if (lane == 0) cd[0] = verdict;
+        }
         __syncthreads();
-        const int gv = cd[0];
-        if (gv < 0) break; // (workgroup-uniform)
-        if ((gv >> 2) == step + 1 && (gv & 3) == AZ_LEAF_EXPAND) {
-            if (tid < 64) rows[tid] = coh_load(rows_x + (size_t)out * 64 + tid);
-            __syncthreads();
+        const int verdict = cd[0];
+        if (verdict < 0) break; // (workgroup-uniform)
+        if (verdict == 1) {
             for (int i = tid; i < 2 * G::SIZE; i += G::NTHR) { // the planes as select writes them (write_board)
                 const int plane = i / G::SIZE, p = i - plane * G::SIZE;
                 planes[i] = (float)(((unsigned)rows[plane * 32 + p / S] >> (p % S)) & 1u);
             }
             __syncthreads();
+#ifdef AZ_CLUSTER_NOEVAL // (timing experiment: the protocol without the network)
+            for (int i = tid; i < G::SIZE; i += G::NTHR) logp[i] = -5.4f;
+            if (tid == 0) value[0] = 0.f;
+#else
             aznet::team_position<G>(ctx, F, W, red, logit, planes, value, logp, tid, wave, lane);
+#endif
             __syncthreads();
-            for (int i = tid; i < G::SIZE; i += G::NTHR)
-                coh_store(reinterpret_cast<int *>(d_logp) + (size_t)out * G::SIZE + i, __float_as_int(logp[i]));
-            if (tid == 0) coh_store(reinterpret_cast<int *>(d_value) + out, __float_as_int(value[0]));
-            coh_stores_done(); // this wavefront's outputs have arrived ...
-            __syncthreads();   // ... and so have everyone's
-            if (tid == 0) coh_store(&done[out], step + 1);
+            unsigned long long *res = result_x + (size_t)out * CLUSTER_RESULT;
+            for (int i = tid; i < G::SIZE; i += G::NTHR) coh_store_tagged(res + i, step + 1, (unsigned)__float_as_int(logp[i]));
+            if (tid == 0) coh_store_tagged(res + G::SIZE, step + 1, (unsigned)__float_as_int(value[0]));
+            // (logp and value are written again only after the next step's barriers)
         }
     }
 }
@@ -2392,7 +2446,7 @@ int l_net_search(const AzParams &P, int th_num, int per, const float *d_params, 
 // returns 0 when launched, 1 when a launch was tried and failed, 2 when this device cannot hold the grid at once
 // (the caller then takes the stepped launches)
 int l_net_search_workers(const AzParams &P, int nw, int per, const float *d_params, int front, int pol, int val, int *d_leaf_kind,
-                         float *d_value, float *d_logp, int *d_flags, void *stream)
+                         int *d_flags, void *stream)
 {
     const size_t lds_bytes = (size_t)NET_SEARCH_LDS_FLOATS * sizeof(float);
     static int blocks_per_cu[64] = {};
@@ -2413,7 +2467,7 @@ int l_net_search_workers(const AzParams &P, int nw, int per, const float *d_para
     const int grid = P.n_trees * (nw + 1);
     if (nw > 8 || grid > cus) return 2; // (one workgroup per CU: a team then has its CU's matrix cores to itself)
     AzParams Pv = P;
-    void *args[] = {&Pv, &nw, &per, &d_params, &front, &pol, &val, &d_leaf_kind, &d_value, &d_logp, &d_flags};
+    void *args[] = {&Pv, &nw, &per, &d_params, &front, &pol, &val, &d_leaf_kind, &d_flags};
     if (hipLaunchCooperativeKernel((const void *)k_net_search_workers, dim3(grid), dim3(NetG::NTHR), args, (unsigned)lds_bytes,
                                    (hipStream_t)stream) != hipSuccess) {
         (void)hipGetLastError();

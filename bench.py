@@ -504,7 +504,8 @@ def one_tree_latency(torch, dev_index, sims=800):
             torch.manual_seed(0)
             ev = FusedNetEvaluator(PolicyValueNet(shape).eval(), shape, dev)
             # threads 0: one worker; 4 (general_config.py:72) and 8 (config.py:65): the reference's shipped settings,
-            # here concurrent workers in lock step (their leaves in one evaluator launch per step)
+            # here concurrent workers in lock step (one launch for the whole call: a master workgroup and an evaluator
+            # team per worker)
             for threads in (0, 4, 8):
                 tb = sp.TreeBatch(1, shape, ev, cpuct=CPUCT, eps=0.25, threads=threads, nodes_per_tree=4 * sims + 64,
                                   device=dev_index)
@@ -519,6 +520,9 @@ def one_tree_latency(torch, dev_index, sims=800):
                     tag = f"{shape}x{shape}" + (f"_threads{threads}" if threads else "")
                     out[f"ms_per_simulate_{tag}"] = dt * 1e3
                     out[f"us_per_search_{tag}"] = dt / sims * 1e6
+                    # which launch sequence ran: 2 = one launch (k_net_search), 3 = the cluster of a master and one
+                    # evaluator team per worker (k_net_search_workers), 1 = stepped launches
+                    out[f"net_path_{tag}"] = tb.eng.get_net_path()
                 finally:
                     tb.close()
     except Exception as e:

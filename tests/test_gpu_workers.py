@@ -382,7 +382,7 @@ def test_one_launch_cluster_search_equals_the_stepped_launches(B, S, T, sims, mo
     for ply in range(plies):
         monkeypatch.delenv("AZ_NET_SEARCH", raising=False)
         a.simulate_net(sims, ev.params.data_ptr(), ev.fused_layers, stream)
-        assert a.get_net_path() == E.NET_PATH_CLUSTER
+        assert a.get_net_path() == E.NET_PATH_CLUSTER, (a.get_net_path(), B, S, T, sims)
         monkeypatch.setenv("AZ_NET_SEARCH", "0")
         b.simulate_net(sims, ev.params.data_ptr(), ev.fused_layers, stream)
         assert b.get_net_path() == E.NET_PATH_STEPPED

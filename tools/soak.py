@@ -69,7 +69,7 @@ def main():
         if n_fused % 16 == 0:  # the one-launch cluster search against the stepped launches
             T = int(rng.integers(2, 9))
             TW.test_one_launch_cluster_search_equals_the_stepped_launches(
-                int(rng.integers(1, 256 // (T + 1) + 1)), int(rng.choice([5, 6, 7, 9, 13, 15, 19, 20])), T, int(rng.integers(1, 120)), _Env())
+                int(rng.integers(1, 256 // (T + 1) + 1)), int(rng.choice([5, 6, 7, 9, 13, 15, 19, 20])), T, int(rng.integers(2, 120)), _Env())  # (one search is one worker: not the cluster search)
             os.environ.pop("AZ_NET_SEARCH", None)
             n_cluster += 1
         if n_fused % 48 == 0:

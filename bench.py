@@ -161,7 +161,7 @@ def cpu_baseline(warmup, steps):
         "host": info,
         "note": "kind 'port': the reference itself cannot travel to the GPU box, so the baseline is this repo's CPU restatement of "
                 "cmcts built with -O2.  Per thread it runs about 7x faster than the reference's own tree code probed in the build "
-                "container (about 110 k searches/s at -O2 with a constant prior and no network, BASELINE.md section 2; the reference's "
+                "container (about 110 k searches/s at -O2 with a constant prior and no network, measured once there; the reference's "
                 "shipped flags are -O0): the GPU/CPU ratios in `config` are therefore conservative by about that factor.",
         "independent_value": indep["value"],
         "single_thread_value": single["value"],

@@ -690,9 +690,12 @@ struct NetGroup {
 
 static int net_groups(az_engine *e, int width, void *stream, NetGroup (&g)[AZ_MAX_GROUPS])
 {
-    // two groups once each still fills the evaluator's grid (and stays far above the batch sizes for which az_net_eval
-    // picks its low-latency kernel: a group must get the kernel the whole batch would get)
-    int want = (long long)e->n_trees * width >= 4096 ? 2 : 1;
+    // two groups once each still fills the evaluator's grid (and stays above the batch sizes for which az_net_eval
+    // picks its low-latency kernel: a group must get the kernel the whole batch would get).  Measured at 15x15, one
+    // group against two, M searches/s by leaves per step: 1024: 15.5 / 13.2 and 23.1 / 11.2; 2048: 21.9 / 24.2 and
+    // 19.0 / 20.9; 2560: 14.6 / 20.4; 4096: 23.9 / 25.3; at 20x20 (two wavefronts per position in the evaluator) 2048
+    // leaves: 10.6 / 9.9, 4096 and more: two groups ahead
+    int want = (long long)e->n_trees * width >= (e->shape <= 16 ? 2048 : 4096) ? 2 : 1;
     if (const char *w = getenv("AZ_NET_GROUPS")) want = atoi(w); // tuning / test override (the caller then fixes the kernel form)
     if (want > 1 + e->n_aux_streams) want = 1 + e->n_aux_streams;
     if (want < 1) want = 1;

@@ -409,7 +409,7 @@ def test_one_launch_cluster_search_equals_the_stepped_launches(B, S, T, sims, mo
             act[active == 0] = -1
         a.make_move(act)
         b.make_move(act)
-    if S <= 6 and sims >= 30:
+    if S == 5 and sims >= 30:  # (the board fills up: the last searches end on finished games)
         assert a.get_stats()["terminals"] > 0  # searches that ended on a finished game: leaves no team evaluates
     a.close()
     b.close()

@@ -11,13 +11,13 @@ from helpers import ExactTorchEvaluator
 pytestmark = pytest.mark.gpu
 
 
-def _pair(G, S, sims, eps, ev=None, ev1=None, noise_seeds=(0, 0)):
+def _pair(G, S, sims, eps, ev=None, ev1=None, noise_seeds=(0, 0), threads=0):
     from alphazero_amd import selfplay as sp
 
     ev = ExactTorchEvaluator() if ev is None else ev
     ev1 = ev if ev1 is None else ev1
-    return (sp.TreeBatch(G, S, ev, cpuct=4.0, eps=eps, nodes_per_tree=sims * 6, noise_seed=noise_seeds[0]),
-            sp.TreeBatch(G, S, ev1, cpuct=4.0, eps=eps, nodes_per_tree=sims * 6, noise_seed=noise_seeds[1]))
+    return (sp.TreeBatch(G, S, ev, cpuct=4.0, eps=eps, nodes_per_tree=sims * 6 + 64, noise_seed=noise_seeds[0], threads=threads),
+            sp.TreeBatch(G, S, ev1, cpuct=4.0, eps=eps, nodes_per_tree=sims * 6 + 64, noise_seed=noise_seeds[1], threads=threads))
 
 
 def _same_games(a, b):
@@ -81,6 +81,35 @@ def test_resident_self_play_with_the_fused_network_on_the_stepped_path():
     assert stats["sims"] > 0
     decided = sum(1 for g in got if g["r"][0] != np.float32(1e-3))
     assert decided > 0
+
+
+@pytest.mark.parametrize("fused,G,S,threads", [(False, 4, 7, 4), (True, 20, 9, 4), (True, 300, 9, 2)])
+def test_resident_self_play_with_concurrent_workers(fused, G, S, threads):
+    """threads > 1 (the reference's callers play with four, general_config.py:72) inside the resident loop: the workers of
+    every tree in lock step, with an external evaluator (az_select_workers / az_expand_backup_workers), with the fused
+    network on few slots (the one-launch cluster search) and on many (stepped launches); the same games, record for
+    record, as the host-stepped driver with the same worker count."""
+    import torch
+    from alphazero_amd import engine as E
+    from alphazero_amd import selfplay as sp
+    from alphazero_amd.evaluator import FusedNetEvaluator
+    from alphazero_amd.model import PolicyValueNet
+
+    sims, tau, n_games, seed = 26, 2, 2 * G + 3, 13
+    ev = None
+    if fused:
+        torch.manual_seed(4)
+        ev = FusedNetEvaluator(PolicyValueNet(S).eval(), S, 0)
+    b0, b1 = _pair(G, S, sims, 0.25, ev, noise_seeds=(0, 1000), threads=threads)
+    want = sp.self_play_stream(b0, b1, sims, tau, n_games, rng=sp.KeyedUniform(seed))
+    b0.close(); b1.close()
+    b0, b1 = _pair(G, S, sims, 0.25, ev, noise_seeds=(0, 1000), threads=threads)
+    got = sp.self_play_resident(b0, b1, sims, tau, n_games, seed=seed)
+    path = b0.eng.get_net_path()
+    b0.close(); b1.close()
+    _same_games(want, got)
+    if fused:
+        assert path == (E.NET_PATH_CLUSTER if G * (threads + 1) <= 256 else E.NET_PATH_STEPPED)
 
 
 def test_resident_record_arena_overflow_is_reported():

@@ -416,7 +416,7 @@ def secondary_net(torch, E, dev_index, trees=8192, shape=SHAPE, sims=SIMS, label
         return {"workload": label, "error": f"{type(e).__name__}: {e}"}
 
 
-def secondary_games(torch, dev_index, mode, games=4096, shape=SHAPE, sims=100, tau=10, slots=0, resident=False):
+def secondary_games(torch, dev_index, mode, games=4096, shape=SHAPE, sims=100, tau=10, slots=0, resident=False, threads=0):
     """Whole games end to end on one GPU through the batched drivers: `self_play_game`
     (src/self_play.py:134-202; records assembled on the host, as the sample gather takes
     them) or the arena's `eval_game` with two networks and the noise on (src/eval.py:187-209,
@@ -434,8 +434,10 @@ def secondary_games(torch, dev_index, mode, games=4096, shape=SHAPE, sims=100, t
         second = nets[0] if mode == "selfplay" else nets[1]
         nodes = sims * 3 + 64
         width = slots if slots > 0 else games  # trees per batch
-        b0 = sp.TreeBatch(width, shape, nets[0], cpuct=CPUCT, eps=0.25, nodes_per_tree=nodes, device=dev_index, noise_seed=0)
-        b1 = sp.TreeBatch(width, shape, second, cpuct=CPUCT, eps=0.25, nodes_per_tree=nodes, device=dev_index, noise_seed=1000)
+        b0 = sp.TreeBatch(width, shape, nets[0], cpuct=CPUCT, eps=0.25, nodes_per_tree=nodes, device=dev_index, noise_seed=0,
+                          threads=threads)
+        b1 = sp.TreeBatch(width, shape, second, cpuct=CPUCT, eps=0.25, nodes_per_tree=nodes, device=dev_index, noise_seed=1000,
+                          threads=threads)
         try:
             if slots == 0 and not resident:
                 first = np.arange(games, dtype=np.int32) % (shape * shape)  # distinct first stones
@@ -446,7 +448,8 @@ def secondary_games(torch, dev_index, mode, games=4096, shape=SHAPE, sims=100, t
             rec = {"workload": f"{mode}: {games} games of {shape}x{shape} to the end, {sims} sims/move, reference net "
                                f"(seed 0{'' if mode == 'selfplay' else ' vs seed 1'}), eps=0.25, cpuct=4"
                                + (f", {slots} tree slots per batch, a finished game's slot goes to the next game" if slots else "")
-                               + (", game loop resident on the GPU (az_slots_*)" if resident else "")}
+                               + (", game loop resident on the GPU (az_slots_*)" if resident else "")
+                               + (f", {threads} concurrent workers per tree (the reference's THREADS, general_config.py:72)" if threads > 1 else "")}
             loop = None
             if mode == "selfplay" and slots > 0 and resident:
                 data = sp.self_play_resident(b0, b1, sims, tau, games, seed=0)
@@ -769,7 +772,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--only", default=None,
                     help="run one secondary workload alone and print its record (for profiling): "
-                         + ", ".join(list(HASH_WORKLOADS) + ["config3", "config4_share", "config3_games", "config3_stream", "config3_stream_host", "config5_share", "config5_share_host", "config1_one_tree", "concurrent_workers"]))
+                         + ", ".join(list(HASH_WORKLOADS) + ["config3", "config4_share", "config3_games", "config3_stream", "config3_stream_threads4", "config3_stream_host", "config5_share", "config5_share_host", "config1_one_tree", "concurrent_workers"]))
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -814,6 +817,7 @@ def main():
                else config4_share(torch, E, dev_index) if args.only == "config4_share"
                else secondary_games(torch, dev_index, "selfplay") if args.only == "config3_games"
                else secondary_games(torch, dev_index, "selfplay", games=49152, slots=8192, resident=True) if args.only == "config3_stream"
+               else secondary_games(torch, dev_index, "selfplay", games=49152, slots=8192, resident=True, threads=4) if args.only == "config3_stream_threads4"
                else secondary_games(torch, dev_index, "selfplay", games=16384, slots=8192) if args.only == "config3_stream_host"
                else secondary_games(torch, dev_index, "arena", games=32768, slots=16384, resident=True) if args.only == "config5_share"
                else secondary_games(torch, dev_index, "arena") if args.only == "config5_share_host"
@@ -899,6 +903,8 @@ def main():
                 "config3_games": secondary_games(torch, dev_index, "selfplay"),
                 # whole games, the loop resident on the GPU (self_play_resident / eval_games_resident)
                 "config3_stream": secondary_games(torch, dev_index, "selfplay", games=49152, slots=8192, resident=True),
+                # ... with the reference's shipped worker count: four concurrent workers per tree
+                "config3_stream_threads4": secondary_games(torch, dev_index, "selfplay", games=49152, slots=8192, resident=True, threads=4),
                 "config5_share": secondary_games(torch, dev_index, "arena", games=32768, slots=16384, resident=True),
                 # the host-stepped drivers (a host decision per half-move), for comparison
                 "config3_stream_host": secondary_games(torch, dev_index, "selfplay", games=16384, slots=8192),
